@@ -1,0 +1,292 @@
+"""ctypes binding of libddp_hip.so (include/ddp_hip/ddp_hip.h).
+
+Plumbing only: loads the in-tree shared library, mirrors the C structs and exposes thin numpy
+helpers used by tests/ and bench.py.  There is no CPU fallback here or anywhere in the package:
+if the library (or a HIP device) is missing, the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddp_hip.so")
+
+MAX_JOINTS = 64
+
+OK = 0
+EV_LLT_RESTART = 1
+EV_LINESEARCH_FLOOR = 2
+E_ARG, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_MAX_RESTARTS, E_COMM = -1, -2, -3, -4, -5, -6
+
+MODEL_PENDULUM, MODEL_TREE = 0, 1
+EQ_NONE, EQ_CONFIG, EQ_FRAME = 0, 1, 2
+BUILTIN_PENDULUM, BUILTIN_CHAIN6, BUILTIN_TREE38 = 0, 1, 2
+FLAG_NO_TENSORS, FLAG_TRACE = 1, 2
+
+SEQ_NAMES = [
+    "X", "U", "X_NEW", "U_NEW", "LFX", "LFXX", "LX", "LU", "LXX", "LUX", "LUU",
+    "F_VAL", "FX", "FU", "FXX", "FUX", "FUU",
+    "EQ_VAL", "EQ_X", "EQ_U", "EQ_XX", "EQ_UX", "EQ_UU",
+    "MULT_ORIGIN", "MULT_VAL", "MULT_JAC", "FB_ORIGIN", "FB_VAL", "FB_JAC",
+    "VX_TRACE", "VXX_TRACE", "COSTS_OLD", "COSTS_NEW",
+]
+SEQ = {name: i for i, name in enumerate(SEQ_NAMES)}
+
+K_BWD_ASSEMBLE, K_BWD_GAINS, K_FWD_ROLLOUT, K_LIN_FIRST, K_LIN_SECOND = range(5)
+
+# every symbol include/ddp_hip/ddp_hip.h declares
+EXPORTS = [
+    "ddp_hip_abi_version", "ddp_hip_strerror", "ddp_hip_device_count", "ddp_hip_create", "ddp_hip_destroy",
+    "ddp_hip_stream", "ddp_hip_synchronize", "ddp_hip_seq_size", "ddp_hip_device_ptr", "ddp_hip_upload",
+    "ddp_hip_download", "ddp_hip_fill", "ddp_hip_rollout", "ddp_hip_linearize", "ddp_hip_backward",
+    "ddp_hip_forward", "ddp_hip_cost_seq_aug", "ddp_hip_swap_traj", "ddp_hip_profile_enable",
+    "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_comm_unique_id",
+    "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_builtin_model",
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("nv", C.c_int32), ("mass", C.c_double), ("length", C.c_double),
+        ("parent", _ip), ("jtype", _ip), ("axis", _dp), ("Rp", _dp), ("pp", _dp),
+        ("mass_j", _dp), ("com", _dp), ("Ic", _dp), ("gravity", C.c_double * 3),
+    ]
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("model", Model), ("dt", C.c_double), ("c", C.c_double), ("T", C.c_int64), ("batch", C.c_int64),
+        ("eq_kind", C.c_int32), ("eq_advance", C.c_int32), ("ne", _lp), ("eq_target", _dp),
+        ("frame_joint", C.c_int32), ("frame_off", C.c_double * 3),
+        ("first_order_fd", C.c_int32), ("fd_mode", C.c_int32),
+    ]
+
+
+class ModelStorage(C.Structure):
+    _fields_ = [
+        ("parent", C.c_int32 * MAX_JOINTS), ("jtype", C.c_int32 * MAX_JOINTS),
+        ("axis", C.c_double * (MAX_JOINTS * 3)), ("Rp", C.c_double * (MAX_JOINTS * 9)),
+        ("pp", C.c_double * (MAX_JOINTS * 3)), ("mass_j", C.c_double * MAX_JOINTS),
+        ("com", C.c_double * (MAX_JOINTS * 3)), ("Ic", C.c_double * (MAX_JOINTS * 9)),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libddp_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.ddp_hip_abi_version.restype = C.c_int
+    L.ddp_hip_strerror.restype = C.c_char_p
+    L.ddp_hip_strerror.argtypes = [C.c_int]
+    L.ddp_hip_device_count.restype = C.c_int
+    L.ddp_hip_create.argtypes = [C.POINTER(Problem), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.ddp_hip_destroy.argtypes = [C.c_void_p]
+    L.ddp_hip_stream.restype = C.c_void_p
+    L.ddp_hip_stream.argtypes = [C.c_void_p]
+    L.ddp_hip_synchronize.argtypes = [C.c_void_p]
+    L.ddp_hip_seq_size.restype = C.c_int64
+    L.ddp_hip_seq_size.argtypes = [C.c_void_p, C.c_int]
+    L.ddp_hip_device_ptr.restype = C.c_void_p
+    L.ddp_hip_device_ptr.argtypes = [C.c_void_p, C.c_int]
+    L.ddp_hip_upload.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int64]
+    L.ddp_hip_download.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int64]
+    L.ddp_hip_fill.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.ddp_hip_rollout.argtypes = [C.c_void_p]
+    L.ddp_hip_linearize.argtypes = [C.c_void_p]
+    L.ddp_hip_backward.argtypes = [C.c_void_p, _dp, _dp, _lp, C.c_int64]
+    L.ddp_hip_forward.argtypes = [C.c_void_p, _dp, C.c_int32, _dp, _dp]
+    L.ddp_hip_cost_seq_aug.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.ddp_hip_swap_traj.argtypes = [C.c_void_p]
+    L.ddp_hip_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.ddp_hip_profile_reset.argtypes = [C.c_void_p]
+    L.ddp_hip_profile_get.argtypes = [C.c_void_p, C.c_int, _dp, _lp]
+    L.ddp_hip_bwd_algorithmic_bytes.restype = C.c_int64
+    L.ddp_hip_bwd_algorithmic_bytes.argtypes = [C.c_void_p]
+    L.ddp_hip_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+    L.ddp_hip_comm_init.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.ddp_hip_comm_destroy.argtypes = [C.c_void_p]
+    L.ddp_hip_shard_best.argtypes = [C.c_void_p, C.c_double, C.c_int64, _dp, _lp]
+    L.ddp_hip_builtin_model.argtypes = [C.c_int, C.c_uint64, C.POINTER(ModelStorage), C.POINTER(Model)]
+    _lib = L
+    return L
+
+
+class DdpHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: {lib().ddp_hip_strerror(code).decode()} ({code})")
+
+
+def _check(code, where):
+    if code < 0:
+        raise DdpHipError(code, where)
+    return code
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class BuiltinModel:
+    """Seeded model table from the library (ddp_hip_builtin_model), as numpy arrays."""
+
+    def __init__(self, which, seed=0):
+        self.storage = ModelStorage()
+        self.model = Model()
+        _check(lib().ddp_hip_builtin_model(which, seed, C.byref(self.storage), C.byref(self.model)), "builtin_model")
+        nv = self.model.nv
+        self.kind, self.nv = self.model.kind, nv
+        self.mass, self.length = self.model.mass, self.model.length
+        self.gravity = np.array(list(self.model.gravity))
+        st = self.storage
+        self.parent = np.array(st.parent[:nv], dtype=np.int32)
+        self.jtype = np.array(st.jtype[:nv], dtype=np.int32)
+        self.axis = np.array(st.axis[:3 * nv]).reshape(nv, 3)
+        self.Rp = np.array(st.Rp[:9 * nv]).reshape(nv, 3, 3)
+        self.pp = np.array(st.pp[:3 * nv]).reshape(nv, 3)
+        self.mass_j = np.array(st.mass_j[:nv])
+        self.com = np.array(st.com[:3 * nv]).reshape(nv, 3)
+        self.Ic = np.array(st.Ic[:9 * nv]).reshape(nv, 3, 3)
+
+
+class ProblemSpec:
+    """Host-side description of problem_t (problem.hpp:872-1150) for one context."""
+
+    def __init__(self, model, T, dt=0.01, c=1.0, batch=1, eq_kind=EQ_NONE, eq_advance=2, ne=None, eq_target=None,
+                 frame_joint=0, frame_off=(0.0, 0.0, 0.0), first_order_fd=None, fd_mode=0):
+        self.model = model
+        self.T, self.dt, self.c, self.batch = int(T), float(dt), float(c), int(batch)
+        self.eq_kind, self.eq_advance = int(eq_kind), int(eq_advance)
+        self.ne = np.zeros(self.T, dtype=np.int64) if ne is None else np.ascontiguousarray(ne, dtype=np.int64)
+        self.eq_target = _f64(np.zeros(0) if eq_target is None else eq_target)
+        self.frame_joint, self.frame_off = int(frame_joint), tuple(float(v) for v in frame_off)
+        if first_order_fd is None:
+            first_order_fd = 0 if model.kind == MODEL_PENDULUM else 1
+        self.first_order_fd, self.fd_mode = int(first_order_fd), int(fd_mode)
+        self.nv = model.nv
+        self.n, self.m, self.nx = 2 * model.nv, model.nv, 2 * model.nv
+        self.Etot = int(self.ne.sum())
+
+    def c_struct(self):
+        p = Problem()
+        p.model = self.model.model
+        p.dt, p.c, p.T, p.batch = self.dt, self.c, self.T, self.batch
+        p.eq_kind, p.eq_advance = self.eq_kind, self.eq_advance
+        p.ne = self.ne.ctypes.data_as(_lp)
+        p.eq_target = _ptr(self.eq_target) if self.eq_target.size else None
+        p.frame_joint = self.frame_joint
+        p.frame_off = (C.c_double * 3)(*self.frame_off)
+        p.first_order_fd, p.fd_mode = self.first_order_fd, self.fd_mode
+        return p
+
+
+class Context:
+    """One ddp_hip context (= `batch` resident problem instances on one GPU)."""
+
+    def __init__(self, spec, device=0, flags=0):
+        self.spec = spec
+        self._h = C.c_void_p()
+        self._c_problem = spec.c_struct()
+        _check(lib().ddp_hip_create(C.byref(self._c_problem), device, flags, C.byref(self._h)), "ddp_hip_create")
+        self.batch = spec.batch
+
+    def close(self):
+        if self._h:
+            lib().ddp_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seq_size(self, name):
+        return int(lib().ddp_hip_seq_size(self._h, SEQ[name]))
+
+    def device_ptr(self, name):
+        return lib().ddp_hip_device_ptr(self._h, SEQ[name])
+
+    def upload(self, name, arr, first=0, count=None):
+        arr = _f64(arr)
+        count = self.batch - first if count is None else count
+        assert arr.size == self.seq_size(name) * count, (name, arr.size, self.seq_size(name), count)
+        _check(lib().ddp_hip_upload(self._h, SEQ[name], _ptr(arr), first, count), f"upload {name}")
+
+    def download(self, name, first=0, count=None):
+        count = self.batch - first if count is None else count
+        out = np.empty((count, self.seq_size(name)), dtype=np.float64)
+        _check(lib().ddp_hip_download(self._h, SEQ[name], _ptr(out), first, count), f"download {name}")
+        return out
+
+    def fill(self, name, value):
+        _check(lib().ddp_hip_fill(self._h, SEQ[name], float(value)), f"fill {name}")
+
+    def synchronize(self):
+        _check(lib().ddp_hip_synchronize(self._h), "synchronize")
+
+    def rollout(self):
+        return _check(lib().ddp_hip_rollout(self._h), "rollout")
+
+    def linearize(self):
+        return _check(lib().ddp_hip_linearize(self._h), "linearize")
+
+    def backward(self, reg, mu, max_restarts=64):
+        reg = _f64(np.broadcast_to(reg, (self.batch,))).copy()
+        mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
+        restarts = np.zeros(self.batch, dtype=np.int64)
+        rc = _check(lib().ddp_hip_backward(self._h, _ptr(reg), _ptr(mu), restarts.ctypes.data_as(_lp), max_restarts),
+                    "backward")
+        return rc, reg, mu, restarts
+
+    def forward(self, mu, n_alpha=8):
+        mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
+        step = np.zeros(self.batch)
+        dcost = np.zeros(self.batch)
+        rc = _check(lib().ddp_hip_forward(self._h, _ptr(mu), n_alpha, _ptr(step), _ptr(dcost)), "forward")
+        return rc, step, dcost
+
+    def cost_seq_aug(self, which, mu):
+        mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
+        return _check(lib().ddp_hip_cost_seq_aug(self._h, which, _ptr(mu)), "cost_seq_aug")
+
+    def swap_traj(self):
+        _check(lib().ddp_hip_swap_traj(self._h), "swap_traj")
+
+    def profile_enable(self, on=True):
+        _check(lib().ddp_hip_profile_enable(self._h, 1 if on else 0), "profile_enable")
+
+    def profile_reset(self):
+        _check(lib().ddp_hip_profile_reset(self._h), "profile_reset")
+
+    def profile_get(self, kernel_id):
+        ms = C.c_double()
+        n = C.c_int64()
+        _check(lib().ddp_hip_profile_get(self._h, kernel_id, C.byref(ms), C.byref(n)), "profile_get")
+        return ms.value, n.value
+
+    def bwd_algorithmic_bytes(self):
+        return int(lib().ddp_hip_bwd_algorithmic_bytes(self._h))

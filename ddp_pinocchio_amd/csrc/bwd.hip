@@ -1,0 +1,499 @@
+// bwd.hip -- backward (Riccati-like) sweep of augmented-Lagrangian DDP on gfx950.
+//
+// Replaces ddp_solver_t::backward_pass<primal_dual_affine_multipliers> (include/ddp/ddp_bwd.ipp:9-155).
+// The recursion is strictly sequential in t; what is parallel is (a) the independent instances of
+// the batch and (b), inside one step, the columns of Q_xx / Q_ux / Q_uu.  Each step is two launches:
+//
+//   bwd_assemble  grid (jobs, batch): job = a block of x-columns or u-columns.  Streams the
+//                 timestep-contiguous slabs f_xx(:,:,c), f_ux(:,:,c), f_uu(:,:,c) once from HBM with
+//                 16-byte coalesced loads, contracts them with V_x through LDS (tensor.hpp:179-198),
+//                 and adds the dense terms f^T V_xx f (+ multiplier terms) of ddp_bwd.ipp:61-87.
+//                 This is the HBM-bound kernel (0.25 flop/byte).
+//   bwd_gains     grid (batch): LLT of Q_uu + reg I (lower triangle only, fail <=> pivot <= 0,
+//                 ddp_bwd.ipp:104-105), k/K solves (:134-136), V_x / V_xx update (:142-146), all in LDS.
+//
+// A non-positive pivot marks the instance failed; the reg/mu rule of ddp_bwd.ipp:106-110 is applied
+// on the device and the host relaunches the sweep for the failed instances only.
+#include <stdio.h>
+
+#include "internal.h"
+
+namespace {
+
+struct BwdParams {
+  Dims d;
+  const int64_t* ne;
+  const int64_t* Epre;
+  const double *lfx, *lfxx, *lx, *lu, *lxx, *lux, *luu, *fx, *fu, *fxx, *fux, *fuu;
+  const double *eq_val, *eq_x, *eq_u, *eq_xx, *eq_ux, *eq_uu;
+  const double *x, *mult_val, *mult_jac;
+  double *fb_origin, *fb_val, *fb_jac, *vx_trace, *vxx_trace;
+  double *ws_V, *ws_Q, *reg, *mu;
+  int32_t* status;
+  int64_t* restarts;
+  const BwdJob* jobs;
+  int32_t has_tensors;
+};
+
+constexpr int BS = 256;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(BS) void bwd_init(BwdParams p) {
+  const int b = blockIdx.x;
+  const int s = p.status[b];
+  if (s == 2) return;
+  const int64_t n = p.d.n;
+  double* Vx = p.ws_V + (int64_t)b * (n + n * n);
+  double* Vxx = Vx + n;
+  const double* lfx = p.lfx + (int64_t)b * n;
+  const double* lfxx = p.lfxx + (int64_t)b * n * n;
+  for (int64_t i = threadIdx.x; i < n; i += BS) Vx[i] = lfx[i];        // ddp_bwd.ipp:28
+  for (int64_t i = threadIdx.x; i < n * n; i += BS) Vxx[i] = lfxx[i];  // ddp_bwd.ipp:27
+  __syncthreads();
+  if (threadIdx.x == 0 && s == 1) p.status[b] = 0;
+}
+
+// out[j] += sum_i v[i] * Tn[i + j*O]  for j < L   (tensor_view_t::noalias_contract_add_outdim,
+// detail/tensor.hpp:179-198, for one (O x L) slab = one value of the right index).
+// Tn is 16-byte aligned and O is even, so a lane's 16-byte load never straddles a column.
+// Stage 1: every lane loads consecutive double2's (1 KiB per wave instruction) and writes its two-term
+//          partial to LDS at [column][pair] with the column stride padded to O/2+1 (bank-conflict free).
+// Stage 2: lane j sums the O/2 partials of column j in a fixed order (deterministic).
+template <int OC>
+__device__ __forceinline__ void contract_slab(const double* __restrict__ Tn, int O_rt, int L, const double* s_v,
+                                              double* s_part, double* out, int out_stride) {
+  const int O = OC > 0 ? OC : O_rt;
+  const int hp = O >> 1;
+  const int ld = hp + 1;
+  const int total = hp * L;
+  const f64x2* __restrict__ T2 = reinterpret_cast<const f64x2*>(Tn);
+  const int tid = threadIdx.x;
+#pragma unroll 4
+  for (int f = tid; f < total; f += BS) {
+    const f64x2 a = __builtin_nontemporal_load(&T2[f]);
+    const int j = f / hp;
+    const int ip = f - j * hp;
+    s_part[j * ld + ip] = s_v[2 * ip] * a.x + s_v[2 * ip + 1] * a.y;
+  }
+  __syncthreads();
+  for (int j = tid; j < L; j += BS) {
+    double s = 0.0;
+    const double* pj = s_part + j * ld;
+    for (int k = 0; k < hp; ++k) s += pj[k];
+    out[j * out_stride] += s;
+  }
+  __syncthreads();
+}
+
+template <int NC, int MC>
+__global__ __launch_bounds__(BS) void bwd_assemble(BwdParams p, int64_t t) {
+  const int b = blockIdx.y;
+  if (p.status[b] != 0) return;
+  const BwdJob job = p.jobs[blockIdx.x];
+  const int n = NC > 0 ? NC : (int)p.d.n;
+  const int m = MC > 0 ? MC : (int)p.d.m;
+  const int64_t T = p.d.T;
+  const int e = (int)p.ne[t];
+  const int64_t Eo = p.Epre[t];
+  const int64_t Etot = p.d.Etot;
+  const double mu = p.mu[b];
+  const int tid = threadIdx.x;
+  const int kind = job.kind, c0 = job.c0, cn = job.cn;
+  const int rows = kind == 0 ? n + m : m;
+
+  const double* Vx = p.ws_V + (int64_t)b * (n + (int64_t)n * n);
+  const double* Vxx = Vx + n;
+  double* Q = p.ws_Q + (int64_t)b * (n + m + (int64_t)n * n + (int64_t)m * n + (int64_t)m * m);
+  double* Qx = Q;
+  double* Qu = Qx + n;
+  double* Qxx = Qu + m;
+  double* Qux = Qxx + (int64_t)n * n;
+  double* Quu = Qux + (int64_t)m * n;
+
+  const int64_t bt = (int64_t)b * T + t;
+  const double* fx = p.fx + bt * n * n;
+  const double* fu = p.fu + bt * n * m;
+  const double* eqv = p.eq_val + (int64_t)b * Etot + Eo;
+  const double* eqx = p.eq_x + ((int64_t)b * Etot + Eo) * n;
+  const double* equ = p.eq_u + ((int64_t)b * Etot + Eo) * m;
+  const double* pe = p.mult_val + (int64_t)b * Etot + Eo;
+  const double* pex = p.mult_jac + ((int64_t)b * Etot + Eo) * n;
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_v = smem;                         // n
+  double* s_tmp = s_v + n;                    // emax (>= e)
+  double* s_W = s_tmp + p.d.emax;             // n * cn
+  double* s_out = s_W + n * cn;               // rows * cn
+  double* s_part = s_out + (n + m) * cn;      // (n/2+1) * max(n,m)
+
+  for (int i = tid; i < n; i += BS) s_v[i] = Vx[i];
+  for (int i = tid; i < e; i += BS) s_tmp[i] = pe[i] + mu * eqv[i];   // ddp_bwd.ipp:46
+  __syncthreads();
+
+  // W = V_xx * F(:, c0:c0+cn)  with F = f_x (x-job) or f_u (u-job)
+  const double* Fc = (kind == 0 ? fx : fu) + (int64_t)c0 * n;
+  for (int idx = tid; idx < n * cn; idx += BS) {
+    const int r = idx % n, c = idx / n;
+    double s = 0.0;
+    for (int l = 0; l < n; ++l) s += Vxx[r + l * n] * Fc[l + c * n];
+    s_W[idx] = s;
+  }
+  __syncthreads();
+
+  // dense terms, in the reference's order: l, f^T V_xx f, then the multiplier terms
+  for (int idx = tid; idx < rows * cn; idx += BS) {
+    const int r = idx % rows, c = idx / rows;
+    const int col = c0 + c;
+    double acc;
+    const double* Fr;
+    if (kind == 0) {
+      if (r < n) { acc = p.lxx[bt * n * n + r + (int64_t)col * n]; Fr = fx + (int64_t)r * n; }          // :70-71
+      else { acc = p.lux[bt * m * n + (r - n) + (int64_t)col * m]; Fr = fu + (int64_t)(r - n) * n; }   // :83-84
+    } else {
+      acc = p.luu[bt * m * m + r + (int64_t)col * m]; Fr = fu + (int64_t)r * n;                         // :77-78
+    }
+    double s = 0.0;
+    for (int l = 0; l < n; ++l) s += Fr[l] * s_W[l + c * n];
+    acc += s;
+    if (e > 0) {
+      if (kind == 0) {
+        if (r < n) {
+          double s1 = 0.0, s2 = 0.0;
+          for (int i = 0; i < e; ++i) {
+            const double tmp2 = pex[i + col * e] + mu * eqx[i + col * e];   // :47
+            s1 += eqx[i + r * e] * tmp2;                                     // :72
+            s2 += pex[i + r * e] * eqx[i + col * e];                         // :73
+          }
+          acc += s1;
+          acc += s2;
+        } else {
+          double s1 = 0.0;
+          for (int i = 0; i < e; ++i) s1 += equ[i + (r - n) * e] * (pex[i + col * e] + mu * eqx[i + col * e]);  // :85
+          acc += s1;
+        }
+      } else {
+        double s1 = 0.0;
+        for (int i = 0; i < e; ++i) s1 += equ[i + r * e] * equ[i + col * e];
+        acc += s1 * mu;                                                      // :79
+      }
+      if (p.has_tensors) {
+        // multiplier-weighted constraint tensors (:74, :80, :86); e is small, done in place
+        const double* Te;
+        int Ld;
+        int jrow;
+        if (kind == 0) {
+          if (r < n) { Te = p.eq_xx + ((int64_t)b * Etot + Eo) * n * n; Ld = n; jrow = r; }
+          else { Te = p.eq_ux + ((int64_t)b * Etot + Eo) * m * n; Ld = m; jrow = r - n; }
+        } else { Te = p.eq_uu + ((int64_t)b * Etot + Eo) * m * m; Ld = m; jrow = r; }
+        double s3 = 0.0;
+        const double* col_ptr = Te + ((int64_t)jrow + (int64_t)col * Ld) * e;
+        for (int i = 0; i < e; ++i) s3 += s_tmp[i] * col_ptr[i];
+        acc += s3;
+      }
+    }
+    s_out[idx] = acc;
+  }
+  // Q_x / Q_u entries of this job's columns (:61-68)
+  for (int c = tid; c < cn; c += BS) {
+    const int col = c0 + c;
+    double acc, s = 0.0;
+    if (kind == 0) {
+      acc = p.lx[bt * n + col];
+      for (int l = 0; l < n; ++l) s += fx[l + (int64_t)col * n] * s_v[l];
+      acc += s;
+      double s1 = 0.0, s2 = 0.0;
+      for (int i = 0; i < e; ++i) { s1 += eqx[i + col * e] * s_tmp[i]; s2 += pex[i + col * e] * eqv[i]; }
+      acc += s1;
+      acc += s2;
+      Qx[col] = acc;
+    } else {
+      acc = p.lu[bt * m + col];
+      for (int l = 0; l < n; ++l) s += fu[l + (int64_t)col * n] * s_v[l];
+      acc += s;
+      double s1 = 0.0;
+      for (int i = 0; i < e; ++i) s1 += equ[i + col * e] * s_tmp[i];
+      acc += s1;
+      Qu[col] = acc;
+    }
+  }
+  __syncthreads();
+
+  // second-order dynamics tensors contracted with V_x (:75, :81, :87): the HBM stream
+  if (p.has_tensors) {
+    for (int c = 0; c < cn; ++c) {
+      const int col = c0 + c;
+      if (kind == 0) {
+        const double* Txx = p.fxx + (bt * n + col) * (int64_t)n * n;   // f_xx(:,:,col): n x n slab
+        contract_slab<NC>(Txx, n, n, s_v, s_part, s_out + c * rows, 1);
+        const double* Tux = p.fux + (bt * n + col) * (int64_t)n * m;   // f_ux(:,:,col): n x m slab
+        contract_slab<NC>(Tux, n, m, s_v, s_part, s_out + c * rows + n, 1);
+      } else {
+        const double* Tuu = p.fuu + (bt * m + col) * (int64_t)n * m;   // f_uu(:,:,col): n x m slab
+        contract_slab<NC>(Tuu, n, m, s_v, s_part, s_out + c * rows, 1);
+      }
+    }
+  }
+
+  for (int idx = tid; idx < rows * cn; idx += BS) {
+    const int r = idx % rows, c = idx / rows;
+    const int col = c0 + c;
+    if (kind == 0) {
+      if (r < n) Qxx[r + (int64_t)col * n] = s_out[idx];
+      else Qux[(r - n) + (int64_t)col * m] = s_out[idx];
+    } else {
+      Quu[r + (int64_t)col * m] = s_out[idx];
+    }
+  }
+}
+
+template <int NC, int MC>
+__global__ __launch_bounds__(BS) void bwd_gains(BwdParams p, int64_t t) {
+  const int b = blockIdx.x;
+  if (p.status[b] != 0) return;
+  const int n = NC > 0 ? NC : (int)p.d.n;
+  const int m = MC > 0 ? MC : (int)p.d.m;
+  const int nx = (int)p.d.nx;
+  const int64_t T = p.d.T;
+  const int tid = threadIdx.x;
+  const int64_t bt = (int64_t)b * T + t;
+
+  double* Vx = p.ws_V + (int64_t)b * (n + (int64_t)n * n);
+  double* Vxx = Vx + n;
+  const double* Q = p.ws_Q + (int64_t)b * (n + m + (int64_t)n * n + (int64_t)m * n + (int64_t)m * m);
+  const double* Qx = Q;
+  const double* Qu = Qx + n;
+  const double* Qxx = Qu + m;
+  const double* Qux = Qxx + (int64_t)n * n;
+  const double* Quu = Qux + (int64_t)m * n;
+
+  const int lda = m | 1;   // odd leading dimensions: column walks by the lanes are bank-conflict free
+  const int ldr = m | 1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* A = smem;                    // lda * m      Q_uu + reg I, then its Cholesky factor (lower)
+  double* R = A + lda * m;             // ldr * (n+1)  [-Q_u | -Q_ux] -> [k | K]
+  double* S = R + ldr * (n + 1);       // ldr * n      Q_ux
+
+  const double reg = p.reg[b];
+  for (int idx = tid; idx < m * m; idx += BS) {
+    const int i = idx % m, j = idx / m;
+    A[i + j * lda] = Quu[idx] + (i == j ? reg : 0.0);                        // ddp_bwd.ipp:104
+  }
+  for (int i = tid; i < m; i += BS) R[i] = -Qu[i];                           // :135
+  for (int idx = tid; idx < m * n; idx += BS) {
+    const int i = idx % m, j = idx / m;
+    const double q = Qux[idx];
+    R[i + (j + 1) * ldr] = -q;                                               // :136
+    S[i + j * ldr] = q;
+  }
+  __syncthreads();
+
+  // Cholesky, lower triangle only; the update order per entry (k ascending) equals the left-looking
+  // order of Eigen's unblocked LLT.  Failure <=> a pivot is <= 0.
+  bool failed = false;
+  for (int k = 0; k < m; ++k) {
+    const double piv = A[k + k * lda];
+    if (piv <= 0.0) { failed = true; break; }
+    const double dk = sqrt(piv);
+    for (int i = k + 1 + tid; i < m; i += BS) A[i + k * lda] = A[i + k * lda] / dk;
+    __syncthreads();
+    const int w = m - k - 1;
+    for (int idx = tid; idx < w * w; idx += BS) {
+      const int i = k + 1 + idx % w, j = k + 1 + idx / w;
+      if (j <= i) A[i + j * lda] -= A[i + k * lda] * A[j + k * lda];
+    }
+    if (tid == 0) A[k + k * lda] = dk;
+    __syncthreads();
+  }
+  if (failed) {
+    if (tid == 0) {
+      double r = p.reg[b], mu = p.mu[b];
+      if (r < mu) r = mu;          // ddp_bwd.ipp:106-108
+      mu *= 2;                     // :109
+      r *= 2;                      // :110
+      p.reg[b] = r;
+      p.mu[b] = mu;
+      p.status[b] = 1;
+      p.restarts[b] += 1;
+    }
+    return;
+  }
+
+  // k = -(L L^T)^-1 Q_u,  K = -(L L^T)^-1 Q_ux: one right-hand side per lane
+  for (int c = tid; c < n + 1; c += BS) {
+    double* r = R + c * ldr;
+    for (int i = 0; i < m; ++i) {
+      double s = r[i];
+      for (int l = 0; l < i; ++l) s -= A[i + l * lda] * r[l];
+      r[i] = s / A[i + i * lda];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+      double s = r[i];
+      for (int l = i + 1; l < m; ++l) s -= A[l + i * lda] * r[l];
+      r[i] = s / A[i + i * lda];
+    }
+  }
+  __syncthreads();
+
+  double* fbo = p.fb_origin + bt * nx;
+  double* fbk = p.fb_val + bt * m;
+  double* fbK = p.fb_jac + bt * m * n;
+  const double* xt = p.x + ((int64_t)b * (T + 1) + t) * nx;
+  for (int i = tid; i < nx; i += BS) fbo[i] = xt[i];                         // :134
+  for (int i = tid; i < m; i += BS) fbk[i] = R[i];
+  for (int idx = tid; idx < m * n; idx += BS) fbK[idx] = R[idx % m + (idx / m + 1) * ldr];
+
+  // V_x = Q_x + Q_ux^T k (:142-143);  V_xx = Q_xx + Q_ux^T K (:145-146)
+  for (int i = tid; i < n; i += BS) {
+    double s = 0.0;
+    for (int l = 0; l < m; ++l) s += S[l + i * ldr] * R[l];
+    const double v = Qx[i] + s;
+    Vx[i] = v;
+    if (p.vx_trace) p.vx_trace[bt * n + i] = v;
+  }
+  for (int idx = tid; idx < n * n; idx += BS) {
+    const int i = idx % n, j = idx / n;
+    double s = 0.0;
+    const double* si = S + i * ldr;
+    const double* kj = R + (j + 1) * ldr;
+    for (int l = 0; l < m; ++l) s += si[l] * kj[l];
+    const double v = Qxx[idx] + s;
+    Vxx[idx] = v;
+    if (p.vxx_trace) p.vxx_trace[bt * n * n + idx] = v;
+  }
+  if (t == 0 && tid == 0) p.status[b] = 2;                                   // :149-151
+}
+
+size_t assemble_lds_bytes(const ddp_hip_ctx* ctx, int cn_max) {
+  const Dims& d = ctx->d;
+  int64_t L = d.n > d.m ? d.n : d.m;
+  int64_t words = d.n + d.emax + d.n * cn_max + (d.n + d.m) * cn_max + (d.n / 2 + 1) * L;
+  return (size_t)words * sizeof(double);
+}
+size_t gains_lds_bytes(const ddp_hip_ctx* ctx) {
+  const Dims& d = ctx->d;
+  int64_t ld = d.m | 1;
+  return (size_t)(ld * d.m + ld * (d.n + 1) + ld * d.n) * sizeof(double);
+}
+
+BwdParams make_params(ddp_hip_ctx* ctx) {
+  BwdParams p{};
+  p.d = ctx->d;
+  p.ne = ctx->ne_d;
+  p.Epre = ctx->Epre_d;
+  auto S = [&](int s) { return ctx->seq[s].ptr; };
+  p.lfx = S(DDP_HIP_SEQ_LFX); p.lfxx = S(DDP_HIP_SEQ_LFXX);
+  p.lx = S(DDP_HIP_SEQ_LX); p.lu = S(DDP_HIP_SEQ_LU); p.lxx = S(DDP_HIP_SEQ_LXX); p.lux = S(DDP_HIP_SEQ_LUX); p.luu = S(DDP_HIP_SEQ_LUU);
+  p.fx = S(DDP_HIP_SEQ_FX); p.fu = S(DDP_HIP_SEQ_FU);
+  p.fxx = S(DDP_HIP_SEQ_FXX); p.fux = S(DDP_HIP_SEQ_FUX); p.fuu = S(DDP_HIP_SEQ_FUU);
+  p.eq_val = S(DDP_HIP_SEQ_EQ_VAL); p.eq_x = S(DDP_HIP_SEQ_EQ_X); p.eq_u = S(DDP_HIP_SEQ_EQ_U);
+  p.eq_xx = S(DDP_HIP_SEQ_EQ_XX); p.eq_ux = S(DDP_HIP_SEQ_EQ_UX); p.eq_uu = S(DDP_HIP_SEQ_EQ_UU);
+  p.x = S(DDP_HIP_SEQ_X);
+  p.mult_val = S(DDP_HIP_SEQ_MULT_VAL); p.mult_jac = S(DDP_HIP_SEQ_MULT_JAC);
+  p.fb_origin = S(DDP_HIP_SEQ_FB_ORIGIN); p.fb_val = S(DDP_HIP_SEQ_FB_VAL); p.fb_jac = S(DDP_HIP_SEQ_FB_JAC);
+  p.vx_trace = S(DDP_HIP_SEQ_VX_TRACE); p.vxx_trace = S(DDP_HIP_SEQ_VXX_TRACE);
+  p.ws_V = ctx->ws_V; p.ws_Q = ctx->ws_Q; p.reg = ctx->reg_d; p.mu = ctx->mu_d;
+  p.status = ctx->status_d; p.restarts = ctx->restarts_d;
+  p.jobs = ctx->jobs_d;
+  p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
+  return p;
+}
+
+template <int NC, int MC>
+int launch_sweep(ddp_hip_ctx* ctx, const BwdParams& p, size_t lds_a, size_t lds_g) {
+  const Dims& d = ctx->d;
+  hipLaunchKernelGGL(bwd_init, dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p);
+  for (int64_t t = d.T - 1; t >= 0; --t) {
+    prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE);
+    hipLaunchKernelGGL((bwd_assemble<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BS), lds_a, ctx->stream, p, t);
+    prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE);
+    prof_begin(ctx, DDP_HIP_K_BWD_GAINS);
+    hipLaunchKernelGGL((bwd_gains<NC, MC>), dim3((unsigned)d.batch), dim3(BS), lds_g, ctx->stream, p, t);
+    prof_end(ctx, DDP_HIP_K_BWD_GAINS);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDP_HIP_OK;
+}
+
+}  // namespace
+
+int bwd_setup(ddp_hip_ctx* ctx) {
+  const Dims& d = ctx->d;
+  const int64_t n = d.n, m = d.m, B = d.batch;
+  HIP_TRY(hipMalloc(&ctx->ws_V, sizeof(double) * (size_t)(B * (n + n * n))));
+  HIP_TRY(hipMalloc(&ctx->ws_Q, sizeof(double) * (size_t)(B * (n + m + n * n + m * n + m * m))));
+  HIP_TRY(hipMalloc(&ctx->reg_d, sizeof(double) * (size_t)B));
+  HIP_TRY(hipMalloc(&ctx->mu_d, sizeof(double) * (size_t)B));
+  HIP_TRY(hipMalloc(&ctx->status_d, sizeof(int32_t) * (size_t)B));
+  HIP_TRY(hipMalloc(&ctx->restarts_d, sizeof(int64_t) * (size_t)B));
+
+  // column jobs: one x-column streams 3 units (n*n + n*m doubles), one u-column 1 unit (n*m doubles);
+  // aim at >= ~2048 workgroups per launch so that all 256 CUs hold several streaming workgroups
+  int64_t units = 3 * n + m;
+  int64_t want = 2048 / B;
+  if (want < 1) want = 1;
+  if (want > n + m) want = n + m;
+  int64_t upj = (units + want - 1) / want;
+  int64_t cbx = upj / 3; if (cbx < 1) cbx = 1; if (cbx > 8) cbx = 8;
+  int64_t cbu = upj;     if (cbu < 1) cbu = 1; if (cbu > 16) cbu = 16;
+  ctx->cbx = (int32_t)cbx; ctx->cbu = (int32_t)cbu;
+  std::vector<BwdJob> jobs;
+  for (int64_t c = 0; c < n; c += cbx) jobs.push_back(BwdJob{0, (int32_t)c, (int32_t)((n - c) < cbx ? (n - c) : cbx), 0});
+  for (int64_t c = 0; c < m; c += cbu) jobs.push_back(BwdJob{1, (int32_t)c, (int32_t)((m - c) < cbu ? (m - c) : cbu), 0});
+  ctx->njobs = (int32_t)jobs.size();
+  HIP_TRY(hipMalloc(&ctx->jobs_d, sizeof(BwdJob) * jobs.size()));
+  HIP_TRY(hipMemcpy(ctx->jobs_d, jobs.data(), sizeof(BwdJob) * jobs.size(), hipMemcpyHostToDevice));
+  return DDP_HIP_OK;
+}
+
+void bwd_teardown(ddp_hip_ctx* ctx) {
+  if (ctx->ws_V) (void)hipFree(ctx->ws_V);
+  if (ctx->ws_Q) (void)hipFree(ctx->ws_Q);
+  if (ctx->reg_d) (void)hipFree(ctx->reg_d);
+  if (ctx->mu_d) (void)hipFree(ctx->mu_d);
+  if (ctx->status_d) (void)hipFree(ctx->status_d);
+  if (ctx->restarts_d) (void)hipFree(ctx->restarts_d);
+  if (ctx->jobs_d) (void)hipFree(ctx->jobs_d);
+}
+
+extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io, int64_t* restarts_out, int64_t max_restarts) {
+  if (!ctx || !reg_io || !mu_io) return DDP_HIP_E_ARG;
+  const Dims& d = ctx->d;
+  const int64_t B = d.batch;
+  HIP_TRY(hipSetDevice(ctx->device));
+  BwdParams p = make_params(ctx);
+  if (p.has_tensors && (!p.fxx || !p.fux || !p.fuu)) return DDP_HIP_E_UNSUPPORTED;
+
+  HIP_TRY(hipMemcpyAsync(ctx->reg_d, reg_io, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->mu_d, mu_io, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->status_d, 0, sizeof(int32_t) * (size_t)B, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->restarts_d, 0, sizeof(int64_t) * (size_t)B, ctx->stream));
+
+  const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
+  const size_t lds_a = assemble_lds_bytes(ctx, cn_max);
+  const size_t lds_g = gains_lds_bytes(ctx);
+  if (lds_a > 160 * 1024 || lds_g > 160 * 1024) return DDP_HIP_E_UNSUPPORTED;
+
+  std::vector<int32_t> status((size_t)B);
+  bool any_restart = false;
+  int rc = DDP_HIP_OK;
+  for (int64_t attempt = 0;; ++attempt) {
+    if (d.n == 76 && d.m == 38) rc = launch_sweep<76, 38>(ctx, p, lds_a, lds_g);
+    else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6>(ctx, p, lds_a, lds_g);
+    else rc = launch_sweep<0, 0>(ctx, p, lds_a, lds_g);
+    if (rc != DDP_HIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(status.data(), ctx->status_d, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool failed = false;
+    for (int64_t b = 0; b < B; ++b) failed |= status[(size_t)b] == 1;
+    if (!failed) break;
+    any_restart = true;
+    if (max_restarts >= 0 && attempt >= max_restarts) { rc = DDP_HIP_E_MAX_RESTARTS; break; }
+  }
+  HIP_TRY(hipMemcpyAsync(reg_io, ctx->reg_d, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(mu_io, ctx->mu_d, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+  if (restarts_out)
+    HIP_TRY(hipMemcpyAsync(restarts_out, ctx->restarts_d, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (rc != DDP_HIP_OK) return rc;
+  return any_restart ? DDP_HIP_EV_LLT_RESTART : DDP_HIP_OK;
+}

@@ -1,0 +1,116 @@
+// internal.h -- context layout shared by the translation units of libddp_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "ddp_hip/ddp_hip.h"
+
+#define DDP_MAXJ DDP_HIP_MAX_JOINTS
+
+// Device-side model table (tree of 1-DoF joints or the closed-form pendulum); lives in HBM, read
+// through the scalar / L2 path by every dynamics kernel.
+struct DevModel {
+  int32_t kind, nv;
+  double mass, length;
+  double gravity[3];
+  double dt, c;
+  int32_t parent[DDP_MAXJ];
+  int32_t jtype[DDP_MAXJ];
+  double axis[DDP_MAXJ][3];
+  double Rp[DDP_MAXJ][9];
+  double pp[DDP_MAXJ][3];
+  double I6[DDP_MAXJ][21];  // body spatial inertia, packed lower triangle (row-major: (r,c), c<=r at r(r+1)/2+c)
+  // constraint chain
+  int32_t eq_kind, eq_advance, frame_joint, first_order_fd, fd_mode, pad_;
+  double frame_off[3];
+};
+
+// Everything a kernel needs to find a block of a flat sequence.
+struct Dims {
+  int64_t T, n, m, nx, nv, batch;
+  int64_t Etot;   // sum_t ne[t]
+  int64_t emax;
+};
+
+struct SeqBuf {
+  double* ptr = nullptr;   // [batch][size]
+  int64_t size = 0;        // per-instance element count
+};
+
+struct BwdJob {
+  int32_t kind;   // 0: x-columns (Q_xx, Q_ux, Q_x), 1: u-columns (Q_uu, Q_u)
+  int32_t c0, cn;
+  int32_t pad_;
+};
+
+struct ProfSlot {
+  std::vector<hipEvent_t> starts, stops;
+  size_t used = 0;
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+
+struct ddp_hip_ctx {
+  int device = 0;
+  uint32_t flags = 0;
+  hipStream_t stream = nullptr;
+  Dims d{};
+  std::vector<int64_t> ne_h, Epre_h;   // [T], [T+1]
+  int64_t* ne_d = nullptr;             // [T]
+  int64_t* Epre_d = nullptr;           // [T+1] prefix sums of ne
+  double* target_d = nullptr;          // [Etot]
+  DevModel model_h{};
+  DevModel* model_d = nullptr;
+  SeqBuf seq[DDP_HIP_SEQ_COUNT];
+
+  // backward workspace, per instance
+  double* ws_V = nullptr;      // [batch][n + n*n]          V_x | V_xx
+  double* ws_Q = nullptr;      // [batch][n + m + n*n + m*n + m*m]   Q_x | Q_u | Q_xx | Q_ux | Q_uu
+  double* reg_d = nullptr;     // [batch]
+  double* mu_d = nullptr;      // [batch]
+  int32_t* status_d = nullptr; // [batch] 0 active, 1 failed this attempt, 2 done
+  int64_t* restarts_d = nullptr;
+  BwdJob* jobs_d = nullptr;
+  int32_t njobs = 0;
+  int32_t cbx = 0, cbu = 0;
+
+  // forward workspace
+  double* fw_x = nullptr;      // [batch][n_alpha_max][(T+1)*nx]
+  double* fw_u = nullptr;      // [batch][n_alpha_max][T*m]
+  double* fw_dcost = nullptr;  // [batch][n_alpha_max]
+  double* fw_cost_old = nullptr; // [batch]
+  double* step_d = nullptr;    // [batch]
+  int32_t* fw_state_d = nullptr; // [batch] 0 searching, 1 accepted, 2 floor hit
+  double* fw_dcost_acc_d = nullptr; // [batch]
+  int32_t n_alpha_max = 8;
+
+  // linearize workspace
+  double* lin_ws = nullptr;
+  size_t lin_ws_bytes = 0;
+
+  bool profile = false;
+  ProfSlot prof[DDP_HIP_K_COUNT];
+};
+
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e__ = (expr);                            \
+    if (e__ != hipSuccess) { (void)hipGetLastError(); return DDP_HIP_E_HIP; } \
+  } while (0)
+
+// profile helpers (ctx.hip)
+void prof_begin(ddp_hip_ctx* ctx, int kid);
+void prof_end(ddp_hip_ctx* ctx, int kid);
+
+// per-op launchers implemented in their own translation units
+int bwd_setup(ddp_hip_ctx* ctx);
+void bwd_teardown(ddp_hip_ctx* ctx);
+int fwd_setup(ddp_hip_ctx* ctx);
+void fwd_teardown(ddp_hip_ctx* ctx);
+int lin_setup(ddp_hip_ctx* ctx);
+void lin_teardown(ddp_hip_ctx* ctx);
+
+static inline int64_t seq_block_offset_regular(int64_t t, int64_t stride) { return t * stride; }

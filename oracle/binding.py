@@ -1,0 +1,288 @@
+"""ctypes binding of oracle/libddp_oracle.so.  TEST INFRASTRUCTURE ONLY (see ddp_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddp_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class OrcModel(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("nv", C.c_int32), ("mass", C.c_double), ("length", C.c_double),
+        ("parent", _ip), ("jtype", _ip), ("axis", _dp), ("Rp", _dp), ("pp", _dp),
+        ("mass_j", _dp), ("com", _dp), ("Ic", _dp), ("gravity", C.c_double * 3),
+    ]
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [
+        ("model", OrcModel), ("dt", C.c_double), ("c", C.c_double), ("T", C.c_int64),
+        ("eq_kind", C.c_int32), ("eq_advance", C.c_int32), ("ne", _lp), ("eq_target", _dp),
+        ("frame_joint", C.c_int32), ("frame_off", C.c_double * 3),
+        ("first_order_fd", C.c_int32), ("fd_mode", C.c_int32),
+    ]
+
+
+DERIV_FIELDS = ["lfx", "lfxx", "lx", "lu", "lxx", "lux", "luu", "f_val", "fx", "fu", "fxx", "fux", "fuu",
+                "eq_val", "eq_x", "eq_u", "eq_xx", "eq_ux", "eq_uu"]
+
+
+class OrcDerivs(C.Structure):
+    _fields_ = [(k, _dp) for k in DERIV_FIELDS]
+
+
+class OrcAffine(C.Structure):
+    _fields_ = [("origin", _dp), ("val", _dp), ("jac", _dp)]
+
+
+class OrcSolveLog(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("result", C.c_int64), ("mu", C.c_double), ("reg", C.c_double),
+                ("w", C.c_double), ("n", C.c_double), ("last_step", C.c_double), ("opt_obj", C.c_double),
+                ("opt_constr", C.c_double)]
+
+
+def build(force=False, march=None, out=None):
+    """Compiles the oracle with gcc (building the checker is not using it)."""
+    target = out or LIB_PATH
+    if os.path.exists(target) and not force:
+        src = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ddp_oracle.c", "ddp_oracle.h"))
+        if os.path.getmtime(target) >= src:
+            return target
+    flags = ["-O3", f"-march={march or 'x86-64-v3'}", "-ffp-contract=off", "-fPIC", "-std=c99", "-shared"]
+    subprocess.check_call(["gcc", *flags, "-o", target, os.path.join(_HERE, "ddp_oracle.c"), "-lm"])
+    return target
+
+
+_libs = {}
+
+
+def lib(path=None):
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if path == LIB_PATH:
+        build()
+    L = C.CDLL(path)
+    L.orc_aba.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp]
+    L.orc_rnea.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp]
+    L.orc_crba.argtypes = [C.POINTER(OrcModel), _dp, _dp]
+    L.orc_frame_position.argtypes = [C.POINTER(OrcModel), C.c_int32, _dp, _dp, _dp]
+    L.orc_frame_jacobian.argtypes = [C.POINTER(OrcModel), C.c_int32, _dp, _dp, C.c_int, _dp]
+    L.orc_eval_f.argtypes = [C.POINTER(OrcProblem), _dp, _dp, _dp]
+    L.orc_first_order_f.argtypes = [C.POINTER(OrcProblem), _dp, _dp, _dp, _dp, _dp]
+    L.orc_eval_eq.argtypes = [C.POINTER(OrcProblem), C.c_int64, _dp, _dp, _dp]
+    L.orc_cost_seq_aug.argtypes = [C.POINTER(OrcProblem), _dp, _dp, C.POINTER(OrcAffine), C.c_double, _dp]
+    L.orc_compute_derivatives.argtypes = [C.POINTER(OrcProblem), _dp, _dp, C.POINTER(OrcDerivs)]
+    L.orc_rollout.argtypes = [C.POINTER(OrcProblem), _dp, _dp, _dp]
+    L.orc_backward.restype = C.c_int64
+    L.orc_backward.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, _lp, C.POINTER(OrcDerivs), _dp,
+                               C.POINTER(OrcAffine), _dp, _dp, C.POINTER(OrcAffine), _dp, _dp, C.c_int, C.c_int64]
+    L.orc_forward.restype = C.c_double
+    L.orc_forward.argtypes = [C.POINTER(OrcProblem), _dp, _dp, _dp, _dp, C.POINTER(OrcAffine), C.POINTER(OrcAffine),
+                              C.c_double, _lp]
+    L.orc_forward_alpha.restype = C.c_double
+    L.orc_forward_alpha.argtypes = [C.POINTER(OrcProblem), C.c_double, _dp, _dp, _dp, _dp, C.POINTER(OrcAffine),
+                                    C.POINTER(OrcAffine), C.c_double]
+    L.orc_update_origin.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcAffine), _lp, _dp]
+    L.orc_optimality_constr.restype = C.c_double
+    L.orc_optimality_constr.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcDerivs)]
+    L.orc_optimality_obj.restype = C.c_double
+    L.orc_optimality_obj.argtypes = [C.POINTER(OrcProblem), _dp, C.POINTER(OrcAffine), C.c_double, C.POINTER(OrcDerivs)]
+    L.orc_solve.argtypes = [C.POINTER(OrcProblem), C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                            C.c_double, _dp, _dp, _dp, C.POINTER(OrcAffine), C.POINTER(OrcSolveLog)]
+    _libs[path] = L
+    return L
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def deriv_sizes(T, n, m, nx, Etot):
+    return {
+        "lfx": n, "lfxx": n * n, "lx": T * n, "lu": T * m, "lxx": T * n * n, "lux": T * m * n, "luu": T * m * m,
+        "f_val": T * nx, "fx": T * n * n, "fu": T * n * m, "fxx": T * n ** 3, "fux": T * n * m * n, "fuu": T * n * m * m,
+        "eq_val": Etot, "eq_x": Etot * n, "eq_u": Etot * m, "eq_xx": Etot * n * n, "eq_ux": Etot * m * n,
+        "eq_uu": Etot * m * m,
+    }
+
+
+class Oracle:
+    """Problem-bound convenience wrapper.  `model` is any object with the attributes of
+    ddp_pinocchio_amd.capi.BuiltinModel (plain numpy arrays: the oracle never calls the product)."""
+
+    def __init__(self, model, T, dt=0.01, c=1.0, eq_kind=0, eq_advance=2, ne=None, eq_target=None, frame_joint=0,
+                 frame_off=(0, 0, 0), first_order_fd=None, fd_mode=0, lib_path=None):
+        self.L = lib(lib_path)
+        self.nv = int(model.nv)
+        self.T = int(T)
+        self.n, self.m, self.nx = 2 * self.nv, self.nv, 2 * self.nv
+        self._keep = dict(
+            parent=np.ascontiguousarray(model.parent, dtype=np.int32), jtype=np.ascontiguousarray(model.jtype, dtype=np.int32),
+            axis=_f64(model.axis), Rp=_f64(model.Rp), pp=_f64(model.pp), mass_j=_f64(model.mass_j), com=_f64(model.com),
+            Ic=_f64(model.Ic),
+            ne=np.zeros(self.T, dtype=np.int64) if ne is None else np.ascontiguousarray(ne, dtype=np.int64),
+            target=_f64(np.zeros(1) if eq_target is None or len(eq_target) == 0 else eq_target),
+        )
+        k = self._keep
+        self.ne = k["ne"]
+        self.Etot = int(self.ne.sum())
+        m = OrcModel()
+        m.kind, m.nv, m.mass, m.length = int(model.kind), self.nv, float(model.mass), float(model.length)
+        m.parent, m.jtype = k["parent"].ctypes.data_as(_ip), k["jtype"].ctypes.data_as(_ip)
+        m.axis, m.Rp, m.pp, m.mass_j, m.com, m.Ic = _p(k["axis"]), _p(k["Rp"]), _p(k["pp"]), _p(k["mass_j"]), _p(k["com"]), _p(k["Ic"])
+        m.gravity = (C.c_double * 3)(*[float(g) for g in model.gravity])
+        p = OrcProblem()
+        p.model, p.dt, p.c, p.T = m, float(dt), float(c), self.T
+        p.eq_kind, p.eq_advance = int(eq_kind), int(eq_advance)
+        p.ne, p.eq_target = k["ne"].ctypes.data_as(_lp), _p(k["target"])
+        p.frame_joint = int(frame_joint)
+        p.frame_off = (C.c_double * 3)(*[float(v) for v in frame_off])
+        if first_order_fd is None:
+            first_order_fd = 0 if int(model.kind) == 0 else 1
+        p.first_order_fd, p.fd_mode = int(first_order_fd), int(fd_mode)
+        self.p = p
+        self.model = m
+
+    # ---- model level
+    def aba(self, q, v, tau):
+        q, v, tau = _f64(q), _f64(v), _f64(tau)
+        out = np.zeros(self.nv)
+        self.L.orc_aba(C.byref(self.model), _p(q), _p(v), _p(tau), _p(out))
+        return out
+
+    def rnea(self, q, v, a):
+        q, v, a = _f64(q), _f64(v), _f64(a)
+        out = np.zeros(self.nv)
+        self.L.orc_rnea(C.byref(self.model), _p(q), _p(v), _p(a), _p(out))
+        return out
+
+    def crba(self, q):
+        q = _f64(q)
+        out = np.zeros((self.nv, self.nv))
+        self.L.orc_crba(C.byref(self.model), _p(q), _p(out))
+        return out.T.copy()  # column-major -> numpy
+
+    def frame_position(self, joint, off, q):
+        off, q = _f64(off), _f64(q)
+        out = np.zeros(3)
+        self.L.orc_frame_position(C.byref(self.model), joint, _p(off), _p(q), _p(out))
+        return out
+
+    def frame_jacobian(self, joint, off, q, world_aligned=False):
+        off, q = _f64(off), _f64(q)
+        out = np.zeros(3 * self.nv)
+        self.L.orc_frame_jacobian(C.byref(self.model), joint, _p(off), _p(q), int(world_aligned), _p(out))
+        return out.reshape(self.nv, 3).T.copy()
+
+    # ---- dynamics
+    def eval_f(self, x, u):
+        x, u = _f64(x), _f64(u)
+        out = np.zeros(self.nx)
+        self.L.orc_eval_f(C.byref(self.p), _p(x), _p(u), _p(out))
+        return out
+
+    def first_order_f(self, x, u):
+        x, u = _f64(x), _f64(u)
+        fx, fu, f = np.zeros(self.n * self.n), np.zeros(self.n * self.m), np.zeros(self.nx)
+        self.L.orc_first_order_f(C.byref(self.p), _p(x), _p(u), _p(fx), _p(fu), _p(f))
+        return fx, fu, f
+
+    def eval_eq(self, t, x, u):
+        x, u = _f64(x), _f64(u)
+        out = np.zeros(max(int(self.ne[t]), 1))
+        self.L.orc_eval_eq(C.byref(self.p), t, _p(x), _p(u), _p(out))
+        return out[:int(self.ne[t])]
+
+    def rollout(self, x0, us):
+        x0, us = _f64(x0), _f64(us)
+        xs = np.zeros((self.T + 1) * self.nx)
+        self.L.orc_rollout(C.byref(self.p), _p(x0), _p(us), _p(xs))
+        return xs
+
+    def alloc_derivs(self):
+        sz = deriv_sizes(self.T, self.n, self.m, self.nx, self.Etot)
+        return {k: np.zeros(max(v, 1)) for k, v in sz.items()}
+
+    def _derivs_struct(self, d):
+        s = OrcDerivs()
+        for k in DERIV_FIELDS:
+            setattr(s, k, _p(d[k]))
+        return s
+
+    @staticmethod
+    def _affine_struct(a):
+        s = OrcAffine()
+        s.origin, s.val, s.jac = _p(a["origin"]), _p(a["val"]), _p(a["jac"])
+        return s
+
+    def alloc_affine(self, rows_total):
+        return {"origin": np.zeros(self.T * self.nx), "val": np.zeros(max(rows_total, 1)),
+                "jac": np.zeros(max(rows_total * self.n, 1))}
+
+    def compute_derivatives(self, xs, us, d=None):
+        xs, us = _f64(xs), _f64(us)
+        d = d or self.alloc_derivs()
+        s = self._derivs_struct(d)
+        self.L.orc_compute_derivatives(C.byref(self.p), _p(xs), _p(us), C.byref(s))
+        return d
+
+    def cost_seq_aug(self, xs, us, mults, mu):
+        xs, us = _f64(xs), _f64(us)
+        out = np.zeros(self.T + 1)
+        ms = self._affine_struct(mults)
+        self.L.orc_cost_seq_aug(C.byref(self.p), _p(xs), _p(us), C.byref(ms), float(mu), _p(out))
+        return out
+
+    def backward(self, d, xs, mults, reg, mu, trace=True, heap_like=False, max_restarts=64):
+        xs = _f64(xs)
+        fb = self.alloc_affine(self.T * self.m)
+        ds, ms, fs = self._derivs_struct(d), self._affine_struct(mults), self._affine_struct(fb)
+        reg_c, mu_c = C.c_double(reg), C.c_double(mu)
+        vx = np.zeros(self.T * self.n) if trace else None
+        vxx = np.zeros(self.T * self.n * self.n) if trace else None
+        r = self.L.orc_backward(self.T, self.n, self.m, self.nx, self.ne.ctypes.data_as(_lp), C.byref(ds), _p(xs),
+                                C.byref(ms), C.byref(reg_c), C.byref(mu_c), C.byref(fs),
+                                _p(vx) if trace else None, _p(vxx) if trace else None, int(heap_like), max_restarts)
+        return dict(fb=fb, reg=reg_c.value, mu=mu_c.value, restarts=int(r), Vx=vx, Vxx=vxx)
+
+    def forward(self, xs_old, us_old, mults, fb, mu):
+        xs_old, us_old = _f64(xs_old), _f64(us_old)
+        xs_new, us_new = xs_old.copy(), us_old.copy()
+        ms, fs = self._affine_struct(mults), self._affine_struct(fb)
+        ne = C.c_int64()
+        step = self.L.orc_forward(C.byref(self.p), _p(xs_new), _p(us_new), _p(xs_old), _p(us_old), C.byref(ms),
+                                  C.byref(fs), float(mu), C.byref(ne))
+        return step, xs_new, us_new, ne.value
+
+    def forward_alpha(self, step, xs_old, us_old, mults, fb, mu):
+        xs_old, us_old = _f64(xs_old), _f64(us_old)
+        xs_new, us_new = xs_old.copy(), us_old.copy()
+        ms, fs = self._affine_struct(mults), self._affine_struct(fb)
+        dc = self.L.orc_forward_alpha(C.byref(self.p), float(step), _p(xs_new), _p(us_new), _p(xs_old), _p(us_old),
+                                      C.byref(ms), C.byref(fs), float(mu))
+        return dc, xs_new, us_new
+
+    def solve(self, xs, us, mult_jac_seed, max_iterations, threshold, mu, reg, w, n):
+        xs, us = _f64(xs).copy(), _f64(us).copy()
+        seed = _f64(mult_jac_seed if len(mult_jac_seed) else np.zeros(1))
+        fb = self.alloc_affine(self.T * self.m)
+        fs = self._affine_struct(fb)
+        log = OrcSolveLog()
+        self.L.orc_solve(C.byref(self.p), max_iterations, threshold, mu, reg, w, n, _p(seed), _p(xs), _p(us),
+                         C.byref(fs), C.byref(log))
+        return xs, us, fb, {k: getattr(log, k) for k, _ in OrcSolveLog._fields_}

@@ -1,0 +1,116 @@
+"""Backward-sweep parity: HIP path (through the C-ABI) vs the CPU oracle on identical derivative inputs.
+
+Bar: bit-exact flat indexing; <= 1e-10 relative on V_x, V_xx, k, K at every step;
+identical LLT-failure / restart decisions (reg, mu bit-exact).
+"""
+import numpy as np
+import pytest
+
+from synth import rel_err, synth_sweep_inputs, upload_sweep_inputs
+
+TOL = 1e-10   # north_star: within 1e-10 rel on V_x / K (double)
+
+
+def _oracle(nv, T, ne):
+    from ddp_pinocchio_amd import capi
+    from oracle.binding import Oracle
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    model.nv = nv
+    return Oracle(model, T, ne=ne)
+
+
+def _spec(capi, nv, T, ne, batch):
+    if nv == 1:
+        model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    elif nv == 6:
+        model = capi.BuiltinModel(capi.BUILTIN_CHAIN6)
+    elif nv == 38:
+        model = capi.BuiltinModel(capi.BUILTIN_TREE38, 1)
+    else:
+        raise ValueError(nv)
+    ne = np.asarray(ne, dtype=np.int64)
+    kind = capi.EQ_CONFIG if ne.sum() else capi.EQ_NONE
+    return capi.ProblemSpec(model, T, batch=batch, eq_kind=kind, ne=ne, eq_target=np.zeros(int(ne.sum())))
+
+
+def _compare_instance(ctx, b, o, ref, T):
+    n, m, nx = o.n, o.m, o.nx
+    k = ctx.download("FB_VAL", b, 1)[0]
+    K = ctx.download("FB_JAC", b, 1)[0]
+    org = ctx.download("FB_ORIGIN", b, 1)[0]
+    Vx = ctx.download("VX_TRACE", b, 1)[0]
+    Vxx = ctx.download("VXX_TRACE", b, 1)[0]
+    worst = 0.0
+    for t in range(T):
+        for got, exp, w in ((k, ref["fb"]["val"], m), (K, ref["fb"]["jac"], m * n), (Vx, ref["Vx"], n), (Vxx, ref["Vxx"], n * n)):
+            worst = max(worst, rel_err(got[t * w:(t + 1) * w], exp[t * w:(t + 1) * w]))
+    assert np.array_equal(org, ref["fb"]["origin"][:T * nx])   # plain copies: bit exact
+    return worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nv,T,ne_kind,tensors", [
+    (1, 50, "last", True),      # pendulum shape (config P): e = 1 at t = T-2
+    (1, 7, "none", True),
+    (6, 10, "all", True),       # UR5-like shape (config U): e = 6 every step, reference horizon 10
+    (6, 100, "all", True),      # ... BASELINE horizon 100
+    (6, 16, "none", False),     # tensor-free (Gauss-Newton) variant
+    (38, 8, "none", True),      # Talos-like shape at the real n, m with tensors, short horizon
+    (38, 6, "last", True),
+])
+def test_backward_parity(gpu, nv, T, ne_kind, tensors):
+    capi = gpu
+    e = {"last": [0] * (T - 2) + [nv, 0], "all": [nv] * T, "none": [0] * T}[ne_kind]
+    o = _oracle(nv, T, e)
+    batch = 3
+    flags = capi.FLAG_TRACE | (0 if tensors else capi.FLAG_NO_TENSORS)
+    with capi.Context(_spec(capi, nv, T, e, batch), flags=flags) as ctx:
+        refs = []
+        for b in range(batch):
+            d, xs, us, mults = synth_sweep_inputs(T, nv, e, seed=1000 + 17 * b + nv, tensors=tensors)
+            upload_sweep_inputs(ctx, d, xs, us, mults, b, tensors=tensors)
+            refs.append(o.backward(d, xs, mults, reg=0.0, mu=10.0))
+        rc, reg, mu, restarts = ctx.backward(reg=0.0, mu=10.0)
+        assert rc == 0 and not restarts.any()
+        for b in range(batch):
+            assert refs[b]["restarts"] == 0
+            assert reg[b] == refs[b]["reg"] and mu[b] == refs[b]["mu"]
+            worst = _compare_instance(ctx, b, o, refs[b], T)
+            assert worst < TOL, (b, worst)
+
+
+@pytest.mark.gpu
+def test_backward_restart_decisions(gpu):
+    # instance 1 has an indefinite Q_uu at t = 3 -> restarts with the reg/mu rule of ddp_bwd.ipp:105-110;
+    # instances 0 and 2 must be untouched by its restart
+    capi = gpu
+    nv, T = 6, 8
+    e = [0] * T
+    o = _oracle(nv, T, e)
+    with capi.Context(_spec(capi, nv, T, e, 3), flags=capi.FLAG_TRACE) as ctx:
+        refs = []
+        for b in range(3):
+            d, xs, us, mults = synth_sweep_inputs(T, nv, e, seed=50 + b, indefinite_at=3 if b == 1 else None)
+            upload_sweep_inputs(ctx, d, xs, us, mults, b)
+            refs.append(o.backward(d, xs, mults, reg=0.0, mu=0.25))
+        rc, reg, mu, restarts = ctx.backward(reg=0.0, mu=0.25)
+        assert rc == capi.EV_LLT_RESTART
+        assert refs[1]["restarts"] >= 1
+        for b in range(3):
+            assert restarts[b] == refs[b]["restarts"]
+            assert reg[b] == refs[b]["reg"] and mu[b] == refs[b]["mu"]     # bit exact decisions
+            assert _compare_instance(ctx, b, o, refs[b], T) < TOL
+
+
+@pytest.mark.gpu
+def test_backward_max_restarts(gpu):
+    capi = gpu
+    nv, T = 1, 5
+    e = [0] * T
+    with capi.Context(_spec(capi, nv, T, e, 1), flags=capi.FLAG_TRACE) as ctx:
+        d, xs, us, mults = synth_sweep_inputs(T, nv, e, seed=3)
+        d["luu"][:] = -1e30   # never positive definite within the bound
+        upload_sweep_inputs(ctx, d, xs, us, mults, 0)
+        with pytest.raises(capi.DdpHipError) as ei:
+            ctx.backward(reg=0.0, mu=1.0, max_restarts=3)
+        assert ei.value.code == capi.E_MAX_RESTARTS

@@ -1,0 +1,215 @@
+"""Pins the C oracle (oracle/ddp_oracle.c) before it is trusted as the checker of the HIP path.
+
+The reference's own tests hold no golden numbers for the DDP sweep, so the C restatement
+is pinned by (i) an independent numpy restatement and an mpmath high-precision run of the same recursion,
+(ii) closed forms of the pendulum, (iii) rigid-body identities for the from-scratch ABA (Pinocchio, which
+the reference delegates to, is absent), (iv) the engineered LLT-restart case of ddp_bwd.ipp:105-110.
+"""
+import numpy as np
+import pytest
+
+from ddp_pinocchio_amd import capi
+from oracle import np_oracle as npo
+from oracle.binding import Oracle
+from synth import rel_err, synth_sweep_inputs
+
+
+def _fb_arrays(o, res):
+    T, n, m = o.T, o.n, o.m
+    k = res["fb"]["val"][:T * m].reshape(T, m)
+    K = np.stack([res["fb"]["jac"][t * m * n:(t + 1) * m * n].reshape((m, n), order="F") for t in range(T)])
+    Vx = res["Vx"].reshape(T, n)
+    Vxx = np.stack([res["Vxx"][t * n * n:(t + 1) * n * n].reshape((n, n), order="F") for t in range(T)])
+    return k, K, Vx, Vxx
+
+
+@pytest.mark.parametrize("nv,T,ne_kind", [(1, 12, "last"), (3, 9, "all"), (6, 10, "all"), (6, 7, "none"), (4, 6, "ragged")])
+def test_backward_c_vs_numpy(nv, T, ne_kind):
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    model.nv = nv  # only dims matter for the sweep
+    e = {"last": [0] * (T - 2) + [nv, 0], "all": [nv] * T, "none": [0] * T,
+         "ragged": [(t % 3) for t in range(T)]}[ne_kind]
+    o = Oracle(model, T, ne=e)
+    d, xs, us, mults = synth_sweep_inputs(T, nv, e, seed=100 + nv * T)
+    rc = o.backward(d, xs, mults, reg=0.0, mu=10.0)
+    rn = npo.backward_numpy(T, o.n, o.m, o.nx, e, d, xs, mults, 0.0, 10.0)
+    assert rc["restarts"] == 0 and rn["restarts"] == 0
+    k, K, Vx, Vxx = _fb_arrays(o, rc)
+    for a, b in ((k, rn["k"]), (K, rn["K"]), (Vx, rn["Vx"]), (Vxx, rn["Vxx"])):
+        assert rel_err(a, b) < 1e-11
+    assert np.array_equal(rc["fb"]["origin"][:T * o.nx], xs[:T * o.nx])
+
+
+def test_backward_c_vs_mpmath():
+    nv, T = 2, 5
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    model.nv = nv
+    e = [2, 0, 2, 1, 0]
+    o = Oracle(model, T, ne=e)
+    d, xs, us, mults = synth_sweep_inputs(T, nv, e, seed=5)
+    rc = o.backward(d, xs, mults, reg=0.0, mu=10.0)
+    rm = npo.backward_mpmath(T, o.n, o.m, o.nx, e, d, xs, mults, 0.0, 10.0, dps=60)
+    k, K, Vx, Vxx = _fb_arrays(o, rc)
+    for a, b in ((k, rm["k"]), (K, rm["K"]), (Vx, rm["Vx"]), (Vxx, rm["Vxx"])):
+        assert rel_err(a, b) < 1e-12
+
+
+def test_heap_like_variant_is_bit_identical():
+    nv, T = 3, 6
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    model.nv = nv
+    o = Oracle(model, T, ne=[nv] * T)
+    d, xs, us, mults = synth_sweep_inputs(T, nv, [nv] * T, seed=9)
+    a = o.backward(d, xs, mults, 0.0, 10.0, heap_like=False)
+    b = o.backward(d, xs, mults, 0.0, 10.0, heap_like=True)
+    assert np.array_equal(a["fb"]["jac"], b["fb"]["jac"]) and np.array_equal(a["Vxx"], b["Vxx"])
+
+
+def test_llt_restart_rule():
+    # ddp_bwd.ipp:105-110: on a non-positive pivot  reg = max(reg, mu); mu *= 2; reg *= 2; restart
+    nv, T = 3, 6
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    model.nv = nv
+    o = Oracle(model, T, ne=[0] * T)
+    d, xs, us, mults = synth_sweep_inputs(T, nv, [0] * T, seed=11, indefinite_at=3, luu_diag=1.0)
+    r = o.backward(d, xs, mults, reg=0.0, mu=0.25)
+    rn = npo.backward_numpy(T, o.n, o.m, o.nx, [0] * T, d, xs, mults, 0.0, 0.25)
+    assert r["restarts"] >= 1 and r["restarts"] == rn["restarts"]
+    # replay the rule by hand
+    reg, mu = 0.0, 0.25
+    for _ in range(r["restarts"]):
+        reg = max(reg, mu); mu *= 2; reg *= 2
+    assert r["reg"] == reg and r["mu"] == mu and rn["reg"] == reg and rn["mu"] == mu
+    k, K, Vx, Vxx = _fb_arrays(o, r)
+    assert rel_err(K, rn["K"]) < 1e-11 and rel_err(Vxx, rn["Vxx"]) < 1e-11
+
+
+# ---- pendulum closed forms (pendulum_model.hpp:105-130, problem.hpp:441-503) -------------------------
+def test_pendulum_dynamics_closed_form():
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    o = Oracle(model, 4, dt=0.01)
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q, v, u = rng.normal(size=3)
+        acc = -9.81 / 1.0 * np.sin(q) + u / 1.0
+        assert o.aba([q], [v], [u])[0] == acc
+        f = o.eval_f([q, v], [u])
+        assert f[0] == q + 0.01 * v and f[1] == v + acc * 0.01
+        fx, fu, f2 = o.first_order_f([q, v], [u])
+        fx = fx.reshape((2, 2), order="F")
+        assert np.array_equal(f2, f)
+        assert fx[0, 0] == 1.0 and fx[0, 1] == 0.01 and fx[1, 0] == (-9.81 * np.cos(q)) * 0.01 and fx[1, 1] == 1.0
+        assert fu[0] == 0.0 and fu[1] == 0.01
+
+
+def test_fd_first_order_matches_analytic_on_pendulum():
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    oa = Oracle(model, 4, first_order_fd=0)
+    of = Oracle(model, 4, first_order_fd=1)
+    x, u = np.array([0.7, -0.3]), np.array([0.4])
+    fa, ga, _ = oa.first_order_f(x, u)
+    ff, gf, _ = of.first_order_f(x, u)
+    assert np.max(np.abs(fa - ff)) < 5e-8 and np.max(np.abs(ga - gf)) < 5e-8   # FD sanity, not the parity contract
+
+
+def test_fd_second_order_modes_on_pendulum():
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    T = 3
+    xs = np.array([0.3, 0.1, 0.5, -0.2, 0.9, 0.4, 0.0, 0.0])
+    us = np.array([0.2, -0.1, 0.3])
+    d1 = Oracle(model, T, fd_mode=1).compute_derivatives(xs, us)
+    d2 = Oracle(model, T, fd_mode=2).compute_derivatives(xs, us)
+    for t in range(T):
+        q = xs[2 * t]
+        fxx = npo.tens(d1["fxx"], t * 8, 2, 2, 2)
+        expect = 9.81 * np.sin(q) * 0.01   # d/dq of dt * (-g/l cos q)
+        assert abs(fxx[1, 0, 0] - expect) < 1e-7
+        assert np.max(np.abs(np.delete(fxx.ravel(order="F"), 1))) < 1e-7
+        fxx2 = npo.tens(d2["fxx"], t * 8, 2, 2, 2)
+        assert np.max(np.abs(fxx2 - fxx)) < 1e-5
+        assert np.max(np.abs(d2["fuu"][t * 2:(t + 1) * 2])) < 1e-5 and np.max(np.abs(d2["fux"][t * 4:(t + 1) * 4])) < 1e-5
+    # costs: lu = c u, luu = c I (problem.hpp:982-987)
+    assert np.array_equal(d1["lu"][:T], us) and np.array_equal(d1["luu"][:T], np.ones(T))
+
+
+# ---- rigid body dynamics written from scratch (stands in for Pinocchio) ------------------------------
+@pytest.mark.parametrize("which,seed", [(capi.BUILTIN_CHAIN6, 0), (capi.BUILTIN_TREE38, 1), (capi.BUILTIN_TREE38, 2)])
+def test_aba_rnea_crba_identities(which, seed):
+    model = capi.BuiltinModel(which, seed)
+    o = Oracle(model, 2)
+    rng = np.random.default_rng(seed)
+    nv = model.nv
+    for _ in range(3):
+        q, v, tau = rng.normal(size=nv), rng.normal(size=nv), 5 * rng.normal(size=nv)
+        qdd = o.aba(q, v, tau)
+        assert rel_err(o.rnea(q, v, qdd), tau) < 1e-10            # RNEA(q, v, ABA(q, v, tau)) = tau
+        M = o.crba(q)
+        assert np.allclose(M, M.T, atol=1e-10 * np.max(np.abs(M)))
+        assert np.all(np.linalg.eigvalsh(0.5 * (M + M.T)) > 0)
+        h = o.rnea(q, v, np.zeros(nv))
+        assert rel_err(M @ qdd + h, tau) < 1e-10                   # M qdd + h = tau
+
+
+def test_single_revolute_tree_equals_pendulum():
+    # a point mass m at distance l below a revolute y-axis joint is the closed-form pendulum
+    class M:  # plain arrays, tree kind
+        kind, nv, mass, length = 1, 1, 0.0, 0.0
+        parent, jtype = np.array([-1], dtype=np.int32), np.array([0], dtype=np.int32)
+        axis, Rp, pp = np.array([[0.0, 1.0, 0.0]]), np.eye(3)[None], np.zeros((1, 3))
+        mass_j, com, Ic = np.array([1.3]), np.array([[0.0, 0.0, -0.8]]), np.zeros((1, 3, 3))
+        gravity = np.array([0.0, 0.0, -9.81])
+    o = Oracle(M, 2)
+    for q, v, tau in [(0.3, 0.5, 0.2), (-1.1, 2.0, -0.7)]:
+        expect = (-9.81 / 0.8) * np.sin(q) + tau / (1.3 * 0.8 ** 2)
+        assert abs(o.aba([q], [v], [tau])[0] - expect) < 1e-12
+
+
+def test_energy_is_conserved_in_free_motion():
+    model = capi.BuiltinModel(capi.BUILTIN_CHAIN6)
+    o = Oracle(model, 2)
+    q = np.array([0.1, -0.4, 0.8, 0.2, -0.3, 0.5])
+    v = np.array([0.3, -0.2, 0.5, 0.1, 0.4, -0.6])
+    # power balance: d/dt (1/2 v^T M v) = v^T (tau - g(q)) with tau = 0, checked by a central difference
+    def kinetic(q, v): return 0.5 * v @ o.crba(q) @ v
+    grav = o.rnea(q, np.zeros(6), np.zeros(6))
+    qdd = o.aba(q, v, np.zeros(6))
+    h = 1e-6
+    dK = (kinetic(q + h * v, v + h * qdd) - kinetic(q - h * v, v - h * qdd)) / (2 * h)
+    assert abs(dK - (-v @ grav)) < 1e-6 * max(1.0, abs(dK))
+
+
+def test_frame_position_and_jacobians():
+    model = capi.BuiltinModel(capi.BUILTIN_CHAIN6)
+    o = Oracle(model, 2)
+    q = np.array([0.2, -0.5, 0.7, 0.1, 0.4, -0.3])
+    off = [0.0, 0.0, 0.1]
+    J = o.frame_jacobian(5, off, q, world_aligned=True)
+    h = 1e-6
+    for j in range(6):
+        dq = np.zeros(6); dq[j] = h
+        fd = (o.frame_position(5, off, q + dq) - o.frame_position(5, off, q - dq)) / (2 * h)
+        assert np.max(np.abs(fd - J[:, j])) < 1e-8
+    # the reference takes the WORLD-frame jacobian (pinocchio_model.ipp:458-461): J_world = J_aligned - w x p
+    p = o.frame_position(5, off, q)
+    Jw = o.frame_jacobian(5, off, q, world_aligned=False)
+    for j in range(6):
+        # angular part of column j: world axis of joint j; recover it from the two linear parts
+        assert np.max(np.abs((J[:, j] - Jw[:, j]) @ p)) < 1e-12   # (w x p) is orthogonal to p
+
+
+def test_pendulum_solve_approaches_target():
+    # test/pendulum_ddp.cpp shape.  The reference runs this in 1000-digit mpfr with mu = 1e20 and a
+    # multiplier schedule (w /= mu on every update, ddp.hpp:795-798) that underflows double after two or
+    # three updates, so in double the outer loop ends as a penalty method: the terminal
+    # constraint is met to ~1/mu, not to 1e-8.  What is pinned here is that the whole restated loop
+    # (linearise, backward, forward, multiplier logic) drives the pendulum from 0 to the 3.14 rad target.
+    model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+    T = 50
+    ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 1
+    o = Oracle(model, T, dt=0.01, c=1.0, eq_kind=1, eq_advance=2, ne=ne, eq_target=[3.14], fd_mode=2)
+    xs = o.rollout([0.0, 0.0], np.zeros(T))
+    assert abs(xs[2 * T]) < 1e-12
+    xs2, us2, fb, log = o.solve(xs, np.zeros(T), np.zeros(2), max_iterations=40, threshold=1e-8, mu=10.0, reg=0.0,
+                                w=1.0, n=10.0)
+    assert abs(xs2[2 * T] - 3.14) < 0.05, log
+    assert log["opt_constr"] < 0.05 and log["opt_obj"] < 1e-6
