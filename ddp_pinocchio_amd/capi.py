@@ -23,6 +23,7 @@ MODEL_PENDULUM, MODEL_TREE = 0, 1
 EQ_NONE, EQ_CONFIG, EQ_FRAME = 0, 1, 2
 BUILTIN_PENDULUM, BUILTIN_CHAIN6, BUILTIN_TREE38 = 0, 1, 2
 FLAG_NO_TENSORS, FLAG_TRACE = 1, 2
+LIN_COST, LIN_FIRST, LIN_SECOND, LIN_EQ = 1, 2, 4, 8
 
 SEQ_NAMES = [
     "X", "U", "X_NEW", "U_NEW", "LFX", "LFXX", "LX", "LU", "LXX", "LUX", "LUU",
@@ -39,7 +40,8 @@ K_BWD_ASSEMBLE, K_BWD_GAINS, K_FWD_ROLLOUT, K_LIN_FIRST, K_LIN_SECOND = range(5)
 EXPORTS = [
     "ddp_hip_abi_version", "ddp_hip_strerror", "ddp_hip_device_count", "ddp_hip_create", "ddp_hip_destroy",
     "ddp_hip_stream", "ddp_hip_synchronize", "ddp_hip_seq_size", "ddp_hip_device_ptr", "ddp_hip_upload",
-    "ddp_hip_download", "ddp_hip_fill", "ddp_hip_rollout", "ddp_hip_linearize", "ddp_hip_backward",
+    "ddp_hip_download", "ddp_hip_fill", "ddp_hip_rollout", "ddp_hip_linearize", "ddp_hip_linearize_stages",
+    "ddp_hip_backward",
     "ddp_hip_forward", "ddp_hip_cost_seq_aug", "ddp_hip_swap_traj", "ddp_hip_profile_enable",
     "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_comm_unique_id",
     "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_builtin_model",
@@ -106,6 +108,7 @@ def lib():
     L.ddp_hip_fill.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.ddp_hip_rollout.argtypes = [C.c_void_p]
     L.ddp_hip_linearize.argtypes = [C.c_void_p]
+    L.ddp_hip_linearize_stages.argtypes = [C.c_void_p, C.c_uint32]
     L.ddp_hip_backward.argtypes = [C.c_void_p, _dp, _dp, _lp, C.c_int64]
     L.ddp_hip_forward.argtypes = [C.c_void_p, _dp, C.c_int32, _dp, _dp]
     L.ddp_hip_cost_seq_aug.argtypes = [C.c_void_p, C.c_int, _dp]
@@ -251,8 +254,10 @@ class Context:
     def rollout(self):
         return _check(lib().ddp_hip_rollout(self._h), "rollout")
 
-    def linearize(self):
-        return _check(lib().ddp_hip_linearize(self._h), "linearize")
+    def linearize(self, stages=None):
+        if stages is None:
+            return _check(lib().ddp_hip_linearize(self._h), "linearize")
+        return _check(lib().ddp_hip_linearize_stages(self._h, stages), "linearize_stages")
 
     def backward(self, reg, mu, max_restarts=64):
         reg = _f64(np.broadcast_to(reg, (self.batch,))).copy()

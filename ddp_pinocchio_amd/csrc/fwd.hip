@@ -1,7 +1,332 @@
-// fwd.hip -- forward sweep (placeholder until the device ABA lands)
+// fwd.hip -- trajectory rollout, augmented cost and the forward sweep with batched line-search steps.
+//
+// Replaces make_trajectory (ddp.hpp:392-415), cost_seq_aug (ddp.hpp:699-735) and
+// forward_pass<M> (ddp_fwd.ipp:9-67).  A rollout is sequential in t; the independent units are the
+// (instance, step-size candidate) chains: one lane per chain, the candidates of one instance in
+// adjacent lanes so that the gain matrices K_t are fetched once per wave.
+#include <math.h>
+
+#include <vector>
+
 #include "internal.h"
-int fwd_setup(ddp_hip_ctx*) { return DDP_HIP_OK; }
-void fwd_teardown(ddp_hip_ctx*) {}
-extern "C" int ddp_hip_rollout(ddp_hip_ctx*) { return DDP_HIP_E_UNSUPPORTED; }
-extern "C" int ddp_hip_forward(ddp_hip_ctx*, const double*, int32_t, double*, double*) { return DDP_HIP_E_UNSUPPORTED; }
-extern "C" int ddp_hip_cost_seq_aug(ddp_hip_ctx*, int, const double*) { return DDP_HIP_E_UNSUPPORTED; }
+#include "rbd.h"
+
+namespace {
+
+struct FwdParams {
+  Dims d;
+  const DevModel* model;
+  const int64_t* ne;
+  const int64_t* Epre;
+  const double* target;
+  const double *x_old, *u_old;
+  double *x_new, *u_new;
+  const double *fb_val, *fb_jac;
+  const double *mult_origin, *mult_val, *mult_jac;
+  const double* mu;
+  double *costs_old, *costs_new;
+  double *fw_x, *fw_u, *fw_dcost;
+  double* step;
+  double* dcost_acc;
+  int32_t* state;
+  int32_t n_alpha, round;
+};
+
+// constraint value at solver time t: constraint_advance_time_t::eval_to (problem.hpp:563-567) applied
+// eq_advance times around config_constraint_t (:792-806) or spatial_constraint_t (:679-689)
+template <int NJ>
+__device__ void eval_eq(const DevModel& m, const double* target, int e, const double* x, const double* u, double* out) {
+  const int nx = 2 * m.nv;
+  double xa[2 * NJ], xb[2 * NJ];
+  for (int i = 0; i < nx; ++i) xa[i] = x[i];
+  for (int k = 0; k < m.eq_advance; ++k) {
+    rbd::eval_f<NJ>(m, xa, u, xb);
+    for (int i = 0; i < nx; ++i) xa[i] = xb[i];
+  }
+  if (m.eq_kind == DDP_HIP_EQ_CONFIG) {
+    for (int i = 0; i < e; ++i) out[i] = xa[i] - target[i];
+  } else {
+    double p[3];
+    rbd::frame_position<NJ>(m, xa, p, nullptr);
+    for (int i = 0; i < e; ++i) out[i] = p[i] - target[i];
+  }
+}
+
+// one term of cost_seq_aug (ddp.hpp:730): l + pe.ce + mu/2 |ce|^2
+template <int NJ>
+__device__ double stage_cost(const FwdParams& p, const DevModel& m, int b, int64_t t, const double* x, const double* u, double mu) {
+  const int nv = m.nv, n = 2 * nv, nx = 2 * nv;
+  double un = 0;
+  for (int i = 0; i < nv; ++i) un += u[i] * u[i];
+  double cost = 0.5 * m.c * un;                                   // problem_t::l, problem.hpp:937-942
+  const int e = (int)p.ne[t];
+  if (e > 0) {
+    double ce[NJ > 3 ? NJ : 3];
+    const int64_t Eo = p.Epre[t], Etot = p.d.Etot;
+    eval_eq<NJ>(m, p.target + Eo, e, x, u, ce);
+    const double* org = p.mult_origin + ((int64_t)b * p.d.T + t) * nx;
+    const double* val = p.mult_val + (int64_t)b * Etot + Eo;
+    const double* jac = p.mult_jac + ((int64_t)b * Etot + Eo) * n;
+    double dot = 0, sq = 0;
+    for (int i = 0; i < e; ++i) {
+      double pe = val[i];                                         // mat_seq_common.hpp:105-115
+      double s = 0;
+      for (int l = 0; l < n; ++l) s += jac[i + (int64_t)l * e] * (x[l] - org[l]);
+      pe += s;
+      dot += pe * ce[i];
+      sq += ce[i] * ce[i];
+    }
+    cost += dot;
+    cost += (mu / 2) * sq;
+  }
+  return cost;
+}
+
+template <int NJ>
+__global__ void rollout_kernel(FwdParams p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.d.batch) return;
+  const DevModel& m = *p.model;
+  const int nx = 2 * m.nv, nu = m.nv;
+  double* xs = const_cast<double*>(p.x_old) + (int64_t)b * (p.d.T + 1) * nx;
+  const double* us = p.u_old + (int64_t)b * p.d.T * nu;
+  double x[2 * NJ], xn[2 * NJ], u[NJ];
+  for (int i = 0; i < nx; ++i) x[i] = xs[i];
+  for (int64_t t = 0; t < p.d.T; ++t) {
+    for (int i = 0; i < nu; ++i) u[i] = us[t * nu + i];
+    rbd::eval_f<NJ>(m, x, u, xn);
+    for (int i = 0; i < nx; ++i) { x[i] = xn[i]; xs[(t + 1) * nx + i] = xn[i]; }
+  }
+}
+
+// cost_seq_aug of one trajectory: one lane per (instance, t)
+template <int NJ>
+__global__ void cost_kernel(FwdParams p, int which) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t T = p.d.T;
+  if (gid >= p.d.batch * (T + 1)) return;
+  const int b = (int)(gid / (T + 1));
+  const int64_t t = gid % (T + 1);
+  const DevModel& m = *p.model;
+  const int nx = 2 * m.nv, nu = m.nv;
+  double* out = (which == 0 ? p.costs_old : p.costs_new) + (int64_t)b * (T + 1);
+  if (t == T) { out[T] = 0.0; return; }                           // problem_t::lf, problem.hpp:932-936
+  const double* xs = (which == 0 ? p.x_old : p.x_new) + ((int64_t)b * (T + 1) + t) * nx;
+  const double* us = (which == 0 ? p.u_old : p.u_new) + ((int64_t)b * T + t) * nu;
+  double x[2 * NJ], u[NJ];
+  for (int i = 0; i < nx; ++i) x[i] = xs[i];
+  for (int i = 0; i < nu; ++i) u[i] = us[i];
+  out[t] = stage_cost<NJ>(p, m, b, t, x, u, p.mu[b]);
+}
+
+// closed-loop rollouts (ddp_fwd.ipp:39-51) of n_alpha candidate steps per instance + their summed cost
+// difference (ddp_fwd.ipp:54-56)
+template <int NJ>
+__global__ void forward_kernel(FwdParams p) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int na = p.n_alpha;
+  if (gid >= p.d.batch * na) return;
+  const int b = gid / na, a = gid % na;
+  if (p.state[b] != 0) return;
+  const int cand = p.round * na + a;
+  if (cand > 33) { p.fw_dcost[(int64_t)b * na + a] = INFINITY; return; }   // 2^-34 < 1e-10: never tried (ddp_fwd.ipp:35-37)
+  const double step = ldexp(1.0, -cand);
+  const DevModel& m = *p.model;
+  const int nv = m.nv, n = 2 * nv, nx = 2 * nv, nu = nv;
+  const int64_t T = p.d.T;
+  const double mu = p.mu[b];
+  const double* xo = p.x_old + (int64_t)b * (T + 1) * nx;
+  const double* uo = p.u_old + (int64_t)b * T * nu;
+  double* xw = p.fw_x + ((int64_t)b * na + a) * (T + 1) * nx;
+  double* uw = p.fw_u + ((int64_t)b * na + a) * T * nu;
+  const double* cold = p.costs_old + (int64_t)b * (T + 1);
+  double x[2 * NJ], xn[2 * NJ], u[NJ], dx[2 * NJ];
+  const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
+  for (int i = 0; i < nx; ++i) { x[i] = x0[i]; xw[i] = x0[i]; }
+  double dsum = 0.0;
+  for (int64_t t = 0; t < T; ++t) {
+    const double* k = p.fb_val + ((int64_t)b * T + t) * nu;
+    const double* K = p.fb_jac + ((int64_t)b * T + t) * nu * n;
+    for (int i = 0; i < n; ++i) dx[i] = x[i] - xo[t * nx + i];                // :45 difference(out, old, new)
+    for (int i = 0; i < nu; ++i) u[i] = uo[t * nu + i] + step * k[i];         // :47-48
+    for (int i = 0; i < nu; ++i) {
+      double s = 0;
+      for (int l = 0; l < n; ++l) s += K[i + l * nu] * dx[l];
+      u[i] += s;                                                              // :49
+    }
+    for (int i = 0; i < nu; ++i) uw[t * nu + i] = u[i];
+    const double c_new = stage_cost<NJ>(p, m, b, t, x, u, mu);
+    dsum += c_new - cold[t];
+    rbd::eval_f<NJ>(m, x, u, xn);                                             // :50
+    for (int i = 0; i < nx; ++i) { x[i] = xn[i]; xw[(t + 1) * nx + i] = xn[i]; }
+  }
+  dsum += 0.0 - cold[T];
+  p.fw_dcost[(int64_t)b * na + a] = dsum;
+}
+
+// accept rule (ddp_fwd.ipp:56-60): the first (= largest) candidate with sum(new - old) <= 0; the winner's
+// trajectory becomes (X_NEW, U_NEW).  grid = batch.
+__global__ void select_kernel(FwdParams p) {
+  const int b = blockIdx.x;
+  if (p.state[b] != 0) return;
+  const int na = p.n_alpha;
+  const int64_t T = p.d.T;
+  const int nx = (int)p.d.nx, nu = (int)p.d.m;
+  __shared__ int s_win, s_last;
+  if (threadIdx.x == 0) {
+    int win = -1, last = -1;
+    for (int a = 0; a < na; ++a) {
+      const int cand = p.round * na + a;
+      if (cand > 33) break;
+      last = a;
+      if (p.fw_dcost[(int64_t)b * na + a] <= 0) { win = a; break; }
+    }
+    s_win = win;
+    s_last = last;
+    const bool floor_hit = (p.round * na + na - 1) >= 33;
+    if (win >= 0) {
+      p.state[b] = 1;
+      p.step[b] = ldexp(1.0, -(p.round * na + win));
+      p.dcost_acc[b] = p.fw_dcost[(int64_t)b * na + win];
+    } else if (floor_hit) {
+      p.state[b] = 2;
+      p.step[b] = ldexp(1.0, -34);                 // the value `step` holds when the loop gives up
+      p.dcost_acc[b] = last >= 0 ? p.fw_dcost[(int64_t)b * na + last] : 0.0;
+    }
+  }
+  __syncthreads();
+  const int src = s_win >= 0 ? s_win : s_last;     // on failure new_traj holds the last rollout tried
+  if (src < 0) return;
+  if (s_win < 0 && (p.round * na + na - 1) < 33) return;
+  const double* xw = p.fw_x + ((int64_t)b * na + src) * (T + 1) * nx;
+  const double* uw = p.fw_u + ((int64_t)b * na + src) * T * nu;
+  double* xn = p.x_new + (int64_t)b * (T + 1) * nx;
+  double* un = p.u_new + (int64_t)b * T * nu;
+  for (int64_t i = threadIdx.x; i < (T + 1) * nx; i += blockDim.x) xn[i] = xw[i];
+  for (int64_t i = threadIdx.x; i < T * nu; i += blockDim.x) un[i] = uw[i];
+}
+
+FwdParams make_params(ddp_hip_ctx* ctx) {
+  FwdParams p{};
+  p.d = ctx->d;
+  p.model = ctx->model_d;
+  p.ne = ctx->ne_d;
+  p.Epre = ctx->Epre_d;
+  p.target = ctx->target_d;
+  auto S = [&](int s) { return ctx->seq[s].ptr; };
+  p.x_old = S(DDP_HIP_SEQ_X); p.u_old = S(DDP_HIP_SEQ_U);
+  p.x_new = S(DDP_HIP_SEQ_X_NEW); p.u_new = S(DDP_HIP_SEQ_U_NEW);
+  p.fb_val = S(DDP_HIP_SEQ_FB_VAL); p.fb_jac = S(DDP_HIP_SEQ_FB_JAC);
+  p.mult_origin = S(DDP_HIP_SEQ_MULT_ORIGIN); p.mult_val = S(DDP_HIP_SEQ_MULT_VAL); p.mult_jac = S(DDP_HIP_SEQ_MULT_JAC);
+  p.mu = ctx->mu_d;
+  p.costs_old = S(DDP_HIP_SEQ_COSTS_OLD); p.costs_new = S(DDP_HIP_SEQ_COSTS_NEW);
+  p.fw_x = ctx->fw_x; p.fw_u = ctx->fw_u; p.fw_dcost = ctx->fw_dcost;
+  p.step = ctx->step_d; p.dcost_acc = ctx->fw_dcost_acc_d; p.state = ctx->fw_state_d;
+  p.n_alpha = ctx->n_alpha_max;
+  p.round = 0;
+  return p;
+}
+
+#define DISPATCH_NJ(nv, CALL)                 \
+  do {                                        \
+    if ((nv) <= 1) { CALL(1); }               \
+    else if ((nv) <= 6) { CALL(6); }          \
+    else if ((nv) <= 38) { CALL(38); }        \
+    else { CALL(64); }                        \
+  } while (0)
+
+}  // namespace
+
+int fwd_setup(ddp_hip_ctx* ctx) {
+  const Dims& d = ctx->d;
+  const int64_t B = d.batch, na = ctx->n_alpha_max;
+  HIP_TRY(hipMalloc(&ctx->fw_x, sizeof(double) * (size_t)(B * na * (d.T + 1) * d.nx)));
+  HIP_TRY(hipMalloc(&ctx->fw_u, sizeof(double) * (size_t)(B * na * d.T * d.m)));
+  HIP_TRY(hipMalloc(&ctx->fw_dcost, sizeof(double) * (size_t)(B * na)));
+  HIP_TRY(hipMalloc(&ctx->step_d, sizeof(double) * (size_t)B));
+  HIP_TRY(hipMalloc(&ctx->fw_dcost_acc_d, sizeof(double) * (size_t)B));
+  HIP_TRY(hipMalloc(&ctx->fw_state_d, sizeof(int32_t) * (size_t)B));
+  return DDP_HIP_OK;
+}
+
+void fwd_teardown(ddp_hip_ctx* ctx) {
+  if (ctx->fw_x) (void)hipFree(ctx->fw_x);
+  if (ctx->fw_u) (void)hipFree(ctx->fw_u);
+  if (ctx->fw_dcost) (void)hipFree(ctx->fw_dcost);
+  if (ctx->step_d) (void)hipFree(ctx->step_d);
+  if (ctx->fw_dcost_acc_d) (void)hipFree(ctx->fw_dcost_acc_d);
+  if (ctx->fw_state_d) (void)hipFree(ctx->fw_state_d);
+}
+
+extern "C" int ddp_hip_rollout(ddp_hip_ctx* ctx) {
+  if (!ctx) return DDP_HIP_E_ARG;
+  HIP_TRY(hipSetDevice(ctx->device));
+  FwdParams p = make_params(ctx);
+  const int bs = 64;
+  const unsigned grid = (unsigned)((ctx->d.batch + bs - 1) / bs);
+#define CALL(NJ) hipLaunchKernelGGL((rollout_kernel<NJ>), dim3(grid), dim3(bs), 0, ctx->stream, p)
+  DISPATCH_NJ(ctx->d.nv, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DDP_HIP_OK;
+}
+
+static int launch_cost(ddp_hip_ctx* ctx, FwdParams& p, int which) {
+  const int bs = 64;
+  const int64_t total = ctx->d.batch * (ctx->d.T + 1);
+  const unsigned grid = (unsigned)((total + bs - 1) / bs);
+#define CALL(NJ) hipLaunchKernelGGL((cost_kernel<NJ>), dim3(grid), dim3(bs), 0, ctx->stream, p, which)
+  DISPATCH_NJ(ctx->d.nv, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  return DDP_HIP_OK;
+}
+
+extern "C" int ddp_hip_cost_seq_aug(ddp_hip_ctx* ctx, int which, const double* mu) {
+  if (!ctx || !mu || (which != 0 && which != 1)) return DDP_HIP_E_ARG;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(ctx->mu_d, mu, sizeof(double) * (size_t)ctx->d.batch, hipMemcpyHostToDevice, ctx->stream));
+  FwdParams p = make_params(ctx);
+  int rc = launch_cost(ctx, p, which);
+  if (rc != DDP_HIP_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DDP_HIP_OK;
+}
+
+extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alpha, double* step_out, double* dcost_out) {
+  if (!ctx || !mu || !step_out || n_alpha < 1 || n_alpha > ctx->n_alpha_max) return DDP_HIP_E_ARG;
+  const Dims& d = ctx->d;
+  const int64_t B = d.batch;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(ctx->mu_d, mu, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->fw_state_d, 0, sizeof(int32_t) * (size_t)B, ctx->stream));
+  FwdParams p = make_params(ctx);
+  p.n_alpha = n_alpha;
+  int rc = launch_cost(ctx, p, 0);                                   // ddp_fwd.ipp:24-26
+  if (rc != DDP_HIP_OK) return rc;
+  std::vector<int32_t> state((size_t)B);
+  const int bs = 64;
+  const unsigned grid = (unsigned)((B * n_alpha + bs - 1) / bs);
+  bool floor_hit = false;
+  for (int round = 0; round * n_alpha <= 33; ++round) {
+    p.round = round;
+    prof_begin(ctx, DDP_HIP_K_FWD_ROLLOUT);
+#define CALL(NJ) hipLaunchKernelGGL((forward_kernel<NJ>), dim3(grid), dim3(bs), 0, ctx->stream, p)
+    DISPATCH_NJ(d.nv, CALL);
+#undef CALL
+    prof_end(ctx, DDP_HIP_K_FWD_ROLLOUT);
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(state.data(), ctx->fw_state_d, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool searching = false;
+    for (int64_t b = 0; b < B; ++b) { searching |= state[(size_t)b] == 0; floor_hit |= state[(size_t)b] == 2; }
+    if (!searching) break;
+  }
+  HIP_TRY(hipMemcpyAsync(step_out, ctx->step_d, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+  if (dcost_out)
+    HIP_TRY(hipMemcpyAsync(dcost_out, ctx->fw_dcost_acc_d, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return floor_hit ? DDP_HIP_EV_LINESEARCH_FLOOR : DDP_HIP_OK;
+}

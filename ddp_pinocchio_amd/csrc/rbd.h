@@ -1,0 +1,291 @@
+// rbd.h -- device rigid-body dynamics for trees of 1-DoF joints (articulated-body algorithm,
+// Featherstone RBDA Table 7.1) and the closed-form pendulum.  Stands in for what the reference
+// delegates to Pinocchio (pinocchio_model.ipp:353-355 aba, :222-321 Lie ops -- vector space here).
+// One thread evaluates one forward dynamics; spatial vectors are [angular; linear].
+#pragma once
+
+#include "internal.h"
+
+namespace rbd {
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+// y = A x, y = A^T x  (row-major 3x3)
+__device__ __forceinline__ void mv3(const double* A, const double* x, double* y) {
+  y[0] = A[0] * x[0] + A[1] * x[1] + A[2] * x[2];
+  y[1] = A[3] * x[0] + A[4] * x[1] + A[5] * x[2];
+  y[2] = A[6] * x[0] + A[7] * x[1] + A[8] * x[2];
+}
+__device__ __forceinline__ void mtv3(const double* A, const double* x, double* y) {
+  y[0] = A[0] * x[0] + A[3] * x[1] + A[6] * x[2];
+  y[1] = A[1] * x[0] + A[4] * x[1] + A[7] * x[2];
+  y[2] = A[2] * x[0] + A[5] * x[1] + A[8] * x[2];
+}
+__device__ __forceinline__ void mm3(const double* A, const double* B, double* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// C = A^T B
+__device__ __forceinline__ void mtm3(const double* A, const double* B, double* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+// E: rotation parent->child coordinates (row-major); r: child origin in parent coordinates
+__device__ __forceinline__ void joint_placement(const DevModel& m, int i, double q, double* E, double* r) {
+  const double* Rp = m.Rp[i];
+  const double* a = m.axis[i];
+  if (m.jtype[i] == DDP_HIP_JOINT_REVOLUTE) {
+    double s, c;
+    sincos(q, &s, &c);
+    const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+    double K2[9], RJ[9], Rc[9];
+    mm3(K, K, K2);
+    const double omc = 1.0 - c;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) RJ[k] = s * K[k] + omc * K2[k];
+    RJ[0] += 1.0; RJ[4] += 1.0; RJ[8] += 1.0;
+    mm3(Rp, RJ, Rc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) E[3 * k + l] = Rc[3 * l + k];
+    r[0] = m.pp[i][0]; r[1] = m.pp[i][1]; r[2] = m.pp[i][2];
+  } else {
+    const double d[3] = {a[0] * q, a[1] * q, a[2] * q};
+    double Rd[3];
+    mv3(Rp, d, Rd);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) E[3 * k + l] = Rp[3 * l + k];
+    r[0] = m.pp[i][0] + Rd[0]; r[1] = m.pp[i][1] + Rd[1]; r[2] = m.pp[i][2] + Rd[2];
+  }
+}
+
+// motion transform parent -> child:  w_c = E w_p ;  v_c = E (v_p - r x w_p)
+__device__ __forceinline__ void xform_motion(const double* E, const double* r, const double* vp, double* vc) {
+  double t[3], u[3];
+  cross3(r, vp, t);
+  u[0] = vp[3] - t[0]; u[1] = vp[4] - t[1]; u[2] = vp[5] - t[2];
+  mv3(E, vp, vc);
+  mv3(E, u, vc + 3);
+}
+// force transform child -> parent (X^T):  f_p = E^T f_c ;  n_p = E^T n_c + r x f_p
+__device__ __forceinline__ void xform_force_T(const double* E, const double* r, const double* fc, double* fp) {
+  double t[3];
+  mtv3(E, fc, fp);
+  mtv3(E, fc + 3, fp + 3);
+  cross3(r, fp + 3, t);
+  fp[0] += t[0]; fp[1] += t[1]; fp[2] += t[2];
+}
+
+// symmetric 6x6, packed lower triangle: (r, c), c <= r, at r(r+1)/2 + c
+__device__ __forceinline__ int sidx(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+
+__device__ __forceinline__ void sym6_mv(const double* I, const double* x, double* y) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s += I[sidx(r, c)] * x[c];
+    y[r] = s;
+  }
+}
+
+// v x m (motion),  v x* f (force)
+__device__ __forceinline__ void crm(const double* v, const double* mm, double* out) {
+  double a[3], b[3], c[3];
+  cross3(v, mm, a);
+  cross3(v + 3, mm, b);
+  cross3(v, mm + 3, c);
+  out[0] = a[0]; out[1] = a[1]; out[2] = a[2];
+  out[3] = b[0] + c[0]; out[4] = b[1] + c[1]; out[5] = b[2] + c[2];
+}
+__device__ __forceinline__ void crf(const double* v, const double* f, double* out) {
+  double a[3], b[3], c[3];
+  cross3(v, f, a);
+  cross3(v + 3, f + 3, b);
+  cross3(v, f + 3, c);
+  out[0] = a[0] + b[0]; out[1] = a[1] + b[1]; out[2] = a[2] + b[2];
+  out[3] = c[0]; out[4] = c[1]; out[5] = c[2];
+}
+
+// IAp (packed) += X^T Ia X  with X = [E 0; -E rx E].
+// Blocks of Ia (child coords): A = ang-ang, B = ang-lin, C = lin-lin.
+//   A' = E^T A E, B' = E^T B E, C' = E^T C E;  C_p = C';  B_p = B' + rx C';
+//   A_p = A' + rx B'^T - B' rx - rx C' rx
+__device__ __forceinline__ void add_xtix(const double* E, const double* r, const double* Ia, double* IAp) {
+  double A[9], B[9], Cc[9], T[9], Ar[9], Br[9], Cr[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      A[3 * i + j] = Ia[sidx(i, j)];
+      B[3 * i + j] = Ia[sidx(i, j + 3)];   // row i (angular), column j+3 (linear)
+      Cc[3 * i + j] = Ia[sidx(i + 3, j + 3)];
+    }
+  mtm3(E, A, T); mm3(T, E, Ar);
+  mtm3(E, B, T); mm3(T, E, Br);
+  mtm3(E, Cc, T); mm3(T, E, Cr);
+  const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+  double rxC[9], Bp[9], rxBt[9], Brx[9], rxCrx[9], BrT[9];
+  mm3(rx, Cr, rxC);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Bp[k] = Br[k] + rxC[k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) BrT[3 * i + j] = Br[3 * j + i];
+  mm3(rx, BrT, rxBt);
+  mm3(Br, rx, Brx);
+  mm3(rxC, rx, rxCrx);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      IAp[sidx(i, j)] += Ar[3 * i + j] + rxBt[3 * i + j] - Brx[3 * i + j] - rxCrx[3 * i + j];
+      IAp[sidx(i + 3, j + 3)] += Cr[3 * i + j];
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) IAp[sidx(j + 3, i)] += Bp[3 * i + j];   // (ang i, lin j) stored at (row j+3, col i)
+}
+
+// pendulum_model.hpp:105-114, g = 9.81 (:26)
+__device__ __forceinline__ double pendulum_acc(const DevModel& m, double q, double tau) {
+  return -9.81 / m.length * sin(q) + tau / m.mass;
+}
+
+// Articulated-body algorithm.  NJ = compile-time bound on the joint count (sizes the per-thread state).
+template <int NJ>
+__device__ void aba_tree(const DevModel& m, const double* q, const double* v, const double* tau, double* qdd) {
+  const int N = m.nv;
+  double E[NJ][9], R[NJ][3], cb[NJ][6], pA[NJ][6], IA[NJ][21], U[NJ][6], Dinv[NJ], uu[NJ];
+  {
+    double vel[NJ][6];
+    for (int i = 0; i < N; ++i) {
+      joint_placement(m, i, q[i], E[i], R[i]);
+      const double* a = m.axis[i];
+      double vJ[6] = {0, 0, 0, 0, 0, 0};
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+      const int par = m.parent[i];
+      if (par >= 0) xform_motion(E[i], R[i], vel[par], vel[i]);
+      else { for (int k = 0; k < 6; ++k) vel[i][k] = 0.0; }
+      for (int k = 0; k < 6; ++k) vel[i][k] += vJ[k];
+      crm(vel[i], vJ, cb[i]);
+      for (int k = 0; k < 21; ++k) IA[i][k] = m.I6[i][k];
+      double Iv[6];
+      sym6_mv(IA[i], vel[i], Iv);
+      crf(vel[i], Iv, pA[i]);
+    }
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    const double* a = m.axis[i];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    double d = 0, sp = 0;
+    for (int r = 0; r < 6; ++r) {
+      const double s = IA[i][sidx(r, o)] * a[0] + IA[i][sidx(r, o + 1)] * a[1] + IA[i][sidx(r, o + 2)] * a[2];
+      U[i][r] = s;
+    }
+    for (int k = 0; k < 3; ++k) { d += a[k] * U[i][o + k]; sp += a[k] * pA[i][o + k]; }
+    Dinv[i] = 1.0 / d;
+    uu[i] = tau[i] - sp;
+    const int par = m.parent[i];
+    if (par >= 0) {
+      double Ia[21], pa[6], Iac[6], fp[6];
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[i][sidx(r, c)] - U[i][r] * U[i][c] * Dinv[i];
+      sym6_mv(Ia, cb[i], Iac);
+      for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (uu[i] * Dinv[i]);
+      add_xtix(E[i], R[i], Ia, IA[par]);
+      xform_force_T(E[i], R[i], pa, fp);
+      for (int k = 0; k < 6; ++k) pA[par][k] += fp[k];
+    }
+  }
+  {
+    double acc[NJ][6];
+    for (int i = 0; i < N; ++i) {
+      double ap[6];
+      const int par = m.parent[i];
+      if (par >= 0) xform_motion(E[i], R[i], acc[par], ap);
+      else {
+        const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+        xform_motion(E[i], R[i], a0, ap);
+      }
+      double s = 0;
+      for (int k = 0; k < 6; ++k) { ap[k] += cb[i][k]; s += U[i][k] * ap[k]; }
+      const double qd = (uu[i] - s) * Dinv[i];
+      qdd[i] = qd;
+      const double* a = m.axis[i];
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
+      acc[i][o] += a[0] * qd; acc[i][o + 1] += a[1] * qd; acc[i][o + 2] += a[2] * qd;
+    }
+  }
+}
+
+// dynamics_t::eval_to, problem.hpp:441-461:  q+ = q + dt v ;  v+ = v + dt * aba(q, v, u)
+template <int NJ>
+__device__ void eval_f(const DevModel& m, const double* x, const double* u, double* x_out) {
+  const int nv = m.nv;
+  if (m.kind == DDP_HIP_MODEL_PENDULUM) {
+    const double acc = pendulum_acc(m, x[0], u[0]);
+    const double vo = m.dt * x[1];
+    x_out[0] = x[0] + vo;
+    x_out[1] = x[1] + acc * m.dt;
+    return;
+  }
+  double acc[NJ];
+  aba_tree<NJ>(m, x, x + nv, u, acc);
+  for (int i = 0; i < nv; ++i) {
+    const double vo = m.dt * x[nv + i];
+    x_out[i] = x[i] + vo;
+    x_out[nv + i] = x[nv + i] + acc[i] * m.dt;
+  }
+}
+
+// world position of a frame fixed at `off` in joint `joint`'s frame (pinocchio_model.ipp:418-430), and
+// optionally the reference's WORLD-frame jacobian rows (pinocchio_model.ipp:433-462): J is 3 x nv, ld 3
+template <int NJ>
+__device__ void frame_position(const DevModel& m, const double* q, double* p3, double* J) {
+  // walk root -> joint along the ancestor chain
+  int chain[NJ];
+  int len = 0;
+  for (int j = m.frame_joint; j >= 0; j = m.parent[j]) chain[len++] = j;
+  double oR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, op[3] = {0, 0, 0};
+  if (J) for (int k = 0; k < 3 * m.nv; ++k) J[k] = 0.0;
+  for (int c = len - 1; c >= 0; --c) {
+    const int i = chain[c];
+    double E[9], r[3], Rc[9], t[3], nR[9];
+    joint_placement(m, i, q[i], E, r);
+    for (int k = 0; k < 3; ++k)
+      for (int l = 0; l < 3; ++l) Rc[3 * k + l] = E[3 * l + k];
+    mv3(oR, r, t);
+    op[0] += t[0]; op[1] += t[1]; op[2] += t[2];
+    mm3(oR, Rc, nR);
+    for (int k = 0; k < 9; ++k) oR[k] = nR[k];
+    if (J) {
+      double aw[3];
+      mv3(oR, m.axis[i], aw);
+      if (m.jtype[i] == DDP_HIP_JOINT_REVOLUTE) {
+        const double lever[3] = {-op[0], -op[1], -op[2]};   // WORLD frame: lever arm to the world origin
+        cross3(aw, lever, J + 3 * i);
+      } else { J[3 * i] = aw[0]; J[3 * i + 1] = aw[1]; J[3 * i + 2] = aw[2]; }
+    }
+  }
+  double t[3];
+  mv3(oR, m.frame_off, t);
+  p3[0] = op[0] + t[0]; p3[1] = op[1] + t[1]; p3[2] = op[2] + t[2];
+}
+
+}  // namespace rbd

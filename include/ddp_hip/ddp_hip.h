@@ -135,6 +135,13 @@ int ddp_hip_fill(ddp_hip_ctx* ctx, int seq, double value);
 int ddp_hip_rollout(ddp_hip_ctx* ctx);
 /* compute_derivatives (problem.hpp:956-998) along (X, U) -> all derivative sequences */
 int ddp_hip_linearize(ddp_hip_ctx* ctx);
+/* the same, stage by stage (cost terms :982-987 | first order f :463-503 | second order f :50-341 |
+ * constraint chain :527-870); the later stages read what the earlier ones left resident */
+#define DDP_HIP_LIN_COST 1u
+#define DDP_HIP_LIN_FIRST 2u
+#define DDP_HIP_LIN_SECOND 4u
+#define DDP_HIP_LIN_EQ 8u
+int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages);
 
 /* backward_pass<primal_dual_affine_multipliers> (ddp_bwd.ipp:9-155).
  * reg_io / mu_io: host arrays [batch], in-out (ddp_bwd.ipp:106-110,154); restarts_out: host [batch] or NULL.

@@ -1,0 +1,40 @@
+"""Shared problem definitions (BASELINE.json configs) for CPU and GPU tests: the same description is
+handed to the product (capi.ProblemSpec) and to the oracle (oracle.binding.Oracle)."""
+import numpy as np
+
+from ddp_pinocchio_amd import capi
+from oracle.binding import Oracle
+
+
+def make(name, T, batch=1, fd_mode=2, seed=1):
+    if name == "pendulum":        # test/pendulum_ddp.cpp: target q = 3.14 at the unshifted time `horizon`
+        model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
+        ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 1
+        kw = dict(eq_kind=capi.EQ_CONFIG, eq_advance=2, ne=ne, eq_target=np.array([3.14]))
+    elif name == "chain6":        # test/pinocchio_ddp.cpp: config constraint to the neutral q at every step
+        model = capi.BuiltinModel(capi.BUILTIN_CHAIN6)
+        ne = np.full(T, 6, dtype=np.int64)
+        kw = dict(eq_kind=capi.EQ_CONFIG, eq_advance=2, ne=ne, eq_target=np.zeros(6 * T))
+    elif name == "chain6_frame":  # test/pinocchio_spatial_eq_ddp.cpp: 3-row frame translation at t = T-2
+        model = capi.BuiltinModel(capi.BUILTIN_CHAIN6)
+        ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 3
+        kw = dict(eq_kind=capi.EQ_FRAME, eq_advance=2, ne=ne, eq_target=np.array([0.3, 0.2, 0.4]), frame_joint=5,
+                  frame_off=(0.0, 0.0, 0.0823))
+    elif name == "tree38":        # Talos-like, unconstrained
+        model = capi.BuiltinModel(capi.BUILTIN_TREE38, seed)
+        kw = dict(eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))
+    else:
+        raise ValueError(name)
+    spec = capi.ProblemSpec(model, T, dt=0.01, c=1.0, batch=batch, fd_mode=fd_mode, **kw)
+    okw = dict(kw)
+    oracle = Oracle(model, T, dt=0.01, c=1.0, fd_mode=fd_mode, **okw)
+    return model, spec, oracle
+
+
+def initial_trajectory(oracle, model, seed, u_sigma=0.1):
+    """x0 = neutral configuration, zero velocity; u_t ~ N(0, u_sigma^2)"""
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros(2 * model.nv)
+    us = u_sigma * rng.normal(size=oracle.T * model.nv)
+    xs = oracle.rollout(x0, us)
+    return x0, us, xs

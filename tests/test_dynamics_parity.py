@@ -1,0 +1,182 @@
+"""Rollout / linearisation / forward-sweep parity: HIP path (C-ABI) vs the CPU oracle.
+
+Tolerances.  The rigid-body arithmetic is restated independently on both sides (structured 3x3 block
+transforms + FMA contraction + ocml sincos on the GPU, dense 6x6 products + no contraction + glibc on the
+CPU), so f(x, u) agrees to a few ulp, not bit for bit.  Finite differences amplify that:
+  first order  (eps = 1.5e-8):  |d f_x| <~ ulp(f) / eps                ~ 1e-7
+  second order (eps = 1.2e-4):  |d f_xx| <~ 2 ulp(f) / eps^2 + 2 |d f_x| / eps ~ 1e-8 + 2e-3 * (f_x noise / 1e-7)
+which is why f_x / f_u are held to 2e-6 and the tensors are compared (a) loosely end to end and (b) tightly
+(1e-5) with the oracle's own f, f_x, f_u resident, which isolates the second-order stencil.
+"""
+import numpy as np
+import pytest
+
+from problems import initial_trajectory, make
+from synth import rel_err
+
+X_TOL = 1e-10
+
+
+def _upload_traj(ctx, xs, us, b=0):
+    ctx.upload("X", xs, b, 1)
+    ctx.upload("U", us, b, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("pendulum", 50), ("chain6", 100), ("tree38", 20)])
+def test_rollout_parity(gpu, name, T):
+    capi = gpu
+    model, spec, o = make(name, T, batch=2)
+    with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
+        refs = []
+        for b in range(2):
+            x0, us, xs = initial_trajectory(o, model, seed=10 + b, u_sigma=1.0)
+            bad = np.full_like(xs, np.nan); bad[:2 * model.nv] = x0
+            _upload_traj(ctx, bad, us, b)
+            refs.append(xs)
+        ctx.rollout()
+        got = ctx.download("X")
+        for b in range(2):
+            assert rel_err(got[b], refs[b]) < X_TOL
+
+
+DERIV_SEQS = {"lfx": "LFX", "lfxx": "LFXX", "lx": "LX", "lu": "LU", "lxx": "LXX", "lux": "LUX", "luu": "LUU",
+              "f_val": "F_VAL", "fx": "FX", "fu": "FU", "eq_val": "EQ_VAL", "eq_x": "EQ_X", "eq_u": "EQ_U"}
+TENSOR_SEQS = {"fxx": "FXX", "fux": "FUX", "fuu": "FUU", "eq_xx": "EQ_XX", "eq_ux": "EQ_UX", "eq_uu": "EQ_UU"}
+
+
+def _abs_err(ctx, d, key, seq):
+    sz = ctx.seq_size(seq)
+    if sz == 0:
+        return 0.0, 0.0
+    got = ctx.download(seq, 0, 1)[0]
+    return float(np.max(np.abs(got - d[key][:sz]))), float(np.max(np.abs(d[key][:sz])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T,fd_mode", [
+    ("pendulum", 50, 2), ("pendulum", 50, 1), ("pendulum", 9, 0),
+    ("chain6", 10, 2), ("chain6_frame", 10, 2), ("tree38", 4, 2), ("tree38", 5, 0),
+])
+def test_linearize_parity(gpu, name, T, fd_mode):
+    capi = gpu
+    model, spec, o = make(name, T, fd_mode=fd_mode)
+    x0, us, xs = initial_trajectory(o, model, seed=3, u_sigma=0.5)
+    d = o.compute_derivatives(xs, us)
+    with capi.Context(spec) as ctx:
+        _upload_traj(ctx, xs, us)
+        ctx.linearize()
+        analytic = model.kind == capi.MODEL_PENDULUM
+        for key, seq in DERIV_SEQS.items():
+            err, scale = _abs_err(ctx, d, key, seq)
+            if key in ("lfx", "lfxx", "lx", "lu", "lxx", "lux", "luu"):
+                assert err == 0.0, key                       # plain arithmetic on the inputs: bit exact
+            elif key in ("f_val", "eq_val"):
+                assert err <= 1e-12 * max(scale, 1.0), (key, err)
+            else:
+                tol = 1e-12 if analytic and key in ("fx", "fu") else 2e-6
+                assert err <= tol * max(scale, 1.0), (key, err, scale)
+        # end to end, every stage on the GPU: bounded by the first-order noise / eps (see module docstring)
+        for key, seq in TENSOR_SEQS.items():
+            err, scale = _abs_err(ctx, d, key, seq)
+            tol = 2e-5 if analytic else 2e-2
+            if fd_mode == 0:
+                assert err == 0.0 and scale == 0.0
+            else:
+                assert err <= tol * max(scale, 1.0), (key, err, scale)
+        if fd_mode == 0:
+            return
+        # second-order stencil in isolation: oracle's f, f_x, f_u (and eq first order) resident
+        for key in ("f_val", "fx", "fu", "eq_val", "eq_x", "eq_u"):
+            sz = ctx.seq_size(DERIV_SEQS[key])
+            if sz:
+                ctx.upload(DERIV_SEQS[key], d[key][:sz], 0, 1)
+        for seq in TENSOR_SEQS.values():
+            if ctx.seq_size(seq):
+                ctx.fill(seq, np.nan)
+        ctx.linearize(capi.LIN_SECOND)
+        for key in ("fxx", "fux", "fuu"):
+            err, scale = _abs_err(ctx, d, key, TENSOR_SEQS[key])
+            assert err <= 1e-5 * max(scale, 1.0), (key, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("pendulum", 50), ("chain6", 10), ("chain6_frame", 12), ("tree38", 12)])
+def test_cost_seq_aug_parity(gpu, name, T):
+    capi = gpu
+    model, spec, o = make(name, T)
+    x0, us, xs = initial_trajectory(o, model, seed=4, u_sigma=0.5)
+    rng = np.random.default_rng(0)
+    mults = o.alloc_affine(o.Etot)
+    mults["origin"][:] = xs[:T * o.nx] + 0.01 * rng.normal(size=T * o.nx)
+    mults["val"][:o.Etot] = rng.normal(size=o.Etot)
+    mults["jac"][:o.Etot * o.n] = rng.normal(size=o.Etot * o.n)
+    ref = o.cost_seq_aug(xs, us, mults, mu=37.0)
+    with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
+        _upload_traj(ctx, xs, us)
+        for k, s in (("origin", "MULT_ORIGIN"), ("val", "MULT_VAL"), ("jac", "MULT_JAC")):
+            if ctx.seq_size(s):
+                ctx.upload(s, mults[k][:ctx.seq_size(s)], 0, 1)
+        ctx.cost_seq_aug(0, 37.0)
+        got = ctx.download("COSTS_OLD", 0, 1)[0]
+        assert rel_err(got, ref) < 1e-11
+        assert got[T] == 0.0
+
+
+def _one_iteration_inputs(o, model, seed, mu):
+    """derivatives + a backward sweep from the oracle: inputs of the forward pass"""
+    x0, us, xs = initial_trajectory(o, model, seed=seed, u_sigma=0.3)
+    d = o.compute_derivatives(xs, us)
+    rng = np.random.default_rng(seed)
+    mults = o.alloc_affine(o.Etot)
+    mults["origin"][:] = xs[:o.T * o.nx]
+    mults["jac"][:o.Etot * o.n] = 0.1 * rng.normal(size=o.Etot * o.n)
+    bw = o.backward(d, xs, mults, reg=0.0, mu=mu)
+    return xs, us, d, mults, bw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T,fd_mode,mu", [("pendulum", 50, 2, 100.0), ("chain6", 10, 2, 100.0), ("tree38", 10, 0, 1.0)])
+def test_forward_parity(gpu, name, T, fd_mode, mu):
+    """Same accepted step as the reference's sequential halving, same new trajectory (ddp_fwd.ipp:9-67)."""
+    capi = gpu
+    model, spec, o = make(name, T, fd_mode=fd_mode)
+    xs, us, d, mults, bw = _one_iteration_inputs(o, model, 21, mu)
+    step_ref, xs_ref, us_ref, n_evals = o.forward(xs, us, mults, bw["fb"], bw["mu"])
+    with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
+        _upload_traj(ctx, xs, us)
+        ctx.upload("X_NEW", xs, 0, 1)
+        ctx.upload("U_NEW", us, 0, 1)
+        for k, s in (("origin", "MULT_ORIGIN"), ("val", "MULT_VAL"), ("jac", "MULT_JAC")):
+            if ctx.seq_size(s):
+                ctx.upload(s, mults[k][:ctx.seq_size(s)], 0, 1)
+        for k, s in (("origin", "FB_ORIGIN"), ("val", "FB_VAL"), ("jac", "FB_JAC")):
+            ctx.upload(s, bw["fb"][k][:ctx.seq_size(s)], 0, 1)
+        rc, step, dcost = ctx.forward(bw["mu"], n_alpha=8)
+        assert step[0] == step_ref, (step, step_ref, n_evals)
+        assert rel_err(ctx.download("X_NEW", 0, 1)[0], xs_ref) < 1e-9
+        assert rel_err(ctx.download("U_NEW", 0, 1)[0], us_ref) < 1e-9
+        dc_ref, _, _ = o.forward_alpha(step_ref, xs, us, mults, bw["fb"], bw["mu"])
+        assert dcost[0] <= 0 and abs(dcost[0] - dc_ref) <= 1e-9 * max(1.0, abs(dc_ref))
+
+
+@pytest.mark.gpu
+def test_forward_line_search_floor(gpu):
+    """A feedback that can only increase the cost: every candidate down to 2^-33 is rejected, the call reports
+    the floor, returns step = 2^-34 and leaves the last tried rollout in X_NEW (ddp_fwd.ipp:35-37,59)."""
+    capi = gpu
+    T = 6
+    model, spec, o = make("pendulum", T, fd_mode=0)
+    spec.eq_kind = capi.EQ_NONE; spec.ne[:] = 0; spec.Etot = 0
+    us = np.zeros(T)
+    xs = o.rollout(np.zeros(2), us)
+    with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
+        _upload_traj(ctx, xs, us)
+        ctx.upload("X_NEW", xs, 0, 1); ctx.upload("U_NEW", us, 0, 1)
+        ctx.upload("FB_ORIGIN", xs[:T * 2], 0, 1)
+        ctx.upload("FB_VAL", np.ones(T), 0, 1)       # u = 0 is optimal for l = c/2 u^2: any step costs more
+        ctx.upload("FB_JAC", np.zeros(T * 2), 0, 1)
+        rc, step, dcost = ctx.forward(1.0, n_alpha=8)
+        assert rc == capi.EV_LINESEARCH_FLOOR
+        assert step[0] == 2.0 ** -34
+        assert np.allclose(ctx.download("U_NEW", 0, 1)[0], 2.0 ** -33)
