@@ -23,14 +23,36 @@ def _upload_traj(ctx, xs, us, b=0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,T", [("pendulum", 50), ("chain6", 100), ("tree38", 20)])
-def test_rollout_parity(gpu, name, T):
+@pytest.mark.parametrize("name", ["pendulum", "chain6", "tree38"])
+def test_single_step_dynamics(gpu, name):
+    """eval_to (problem.hpp:441-461) at random states: the from-scratch device ABA vs the oracle's, a few ulp"""
+    capi = gpu
+    B = 16
+    model, spec, o = make(name, 1, batch=B)
+    rng = np.random.default_rng(0)
+    nx, nv = 2 * model.nv, model.nv
+    with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
+        xs = rng.normal(size=(B, 2 * nx)); us = 3.0 * rng.normal(size=(B, nv))
+        ctx.upload("X", xs); ctx.upload("U", us)
+        ctx.rollout()
+        got = ctx.download("X")
+        for b in range(B):
+            ref = o.eval_f(xs[b, :nx], us[b])
+            assert np.array_equal(got[b, :nx], xs[b, :nx])
+            assert rel_err(got[b, nx:], ref) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T,sigma", [("pendulum", 50, 1.0), ("chain6", 100, 0.05), ("tree38", 20, 1.0)])
+def test_rollout_parity(gpu, name, T, sigma):
+    # long open-loop rollouts of the light UR5-like wrist are chaotic for large torques: keep them gentle,
+    # the arithmetic itself is pinned by test_single_step_dynamics
     capi = gpu
     model, spec, o = make(name, T, batch=2)
     with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
         refs = []
         for b in range(2):
-            x0, us, xs = initial_trajectory(o, model, seed=10 + b, u_sigma=1.0)
+            x0, us, xs = initial_trajectory(o, model, seed=10 + b, u_sigma=sigma)
             bad = np.full_like(xs, np.nan); bad[:2 * model.nv] = x0
             _upload_traj(ctx, bad, us, b)
             refs.append(xs)
@@ -61,8 +83,14 @@ def _abs_err(ctx, d, key, seq):
 def test_linearize_parity(gpu, name, T, fd_mode):
     capi = gpu
     model, spec, o = make(name, T, fd_mode=fd_mode)
-    x0, us, xs = initial_trajectory(o, model, seed=3, u_sigma=0.5)
+    x0, us, xs = initial_trajectory(o, model, seed=3, u_sigma=0.05 if name.startswith("chain6") else 0.5)
     d = o.compute_derivatives(xs, us)
+    # FD noise bounds (module docstring), scaled by the magnitude of f
+    EPS, E1, E2 = 2.220446049250313e-16, 1.4901161193847656e-08, 1.220703125e-04
+    fscale = max(1.0, float(np.max(np.abs(d["f_val"]))))
+    tol_first = 8 * EPS * fscale / E1
+    tol_second_iso = 64 * EPS * fscale / (E2 * E2)
+    tol_second_e2e = tol_second_iso + 4 * tol_first / E2
     with capi.Context(spec) as ctx:
         _upload_traj(ctx, xs, us)
         ctx.linearize()
@@ -74,16 +102,18 @@ def test_linearize_parity(gpu, name, T, fd_mode):
             elif key in ("f_val", "eq_val"):
                 assert err <= 1e-12 * max(scale, 1.0), (key, err)
             else:
-                tol = 1e-12 if analytic and key in ("fx", "fu") else 2e-6
+                tol = 1e-12 if analytic and key in ("fx", "fu") else tol_first * (4 if key.startswith("eq") else 1)
                 assert err <= tol * max(scale, 1.0), (key, err, scale)
         # end to end, every stage on the GPU: bounded by the first-order noise / eps (see module docstring)
         for key, seq in TENSOR_SEQS.items():
             err, scale = _abs_err(ctx, d, key, seq)
-            tol = 2e-5 if analytic else 2e-2
+            tol = tol_second_iso if analytic else tol_second_e2e
+            if key.startswith("eq"):
+                tol *= 8      # two chained dynamics steps per constraint evaluation
             if fd_mode == 0:
                 assert err == 0.0 and scale == 0.0
             else:
-                assert err <= tol * max(scale, 1.0), (key, err, scale)
+                assert err <= tol * max(scale, 1.0), (key, err, scale, tol)
         if fd_mode == 0:
             return
         # second-order stencil in isolation: oracle's f, f_x, f_u (and eq first order) resident
@@ -97,7 +127,7 @@ def test_linearize_parity(gpu, name, T, fd_mode):
         ctx.linearize(capi.LIN_SECOND)
         for key in ("fxx", "fux", "fuu"):
             err, scale = _abs_err(ctx, d, key, TENSOR_SEQS[key])
-            assert err <= 1e-5 * max(scale, 1.0), (key, err, scale)
+            assert err <= tol_second_iso * max(scale, 1.0), (key, err, scale, tol_second_iso)
 
 
 @pytest.mark.gpu
