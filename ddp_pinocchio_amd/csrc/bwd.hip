@@ -15,6 +15,7 @@
 // A non-positive pivot marks the instance failed; the reg/mu rule of ddp_bwd.ipp:106-110 is applied
 // on the device and the host relaunches the sweep for the failed instances only.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "internal.h"
 
@@ -363,6 +364,8 @@ __global__ __launch_bounds__(BS) void bwd_gains(BwdParams p, int64_t t) {
   if (t == 0 && tid == 0) p.status[b] = 2;                                   // :149-151
 }
 
+#include "bwd_fast.h"
+
 size_t assemble_lds_bytes(const ddp_hip_ctx* ctx, int cn_max) {
   const Dims& d = ctx->d;
   int64_t L = d.n > d.m ? d.n : d.m;
@@ -398,16 +401,22 @@ BwdParams make_params(ddp_hip_ctx* ctx) {
   return p;
 }
 
-template <int NC, int MC>
+template <int NC, int MC, bool FAST>
 int launch_sweep(ddp_hip_ctx* ctx, const BwdParams& p, size_t lds_a, size_t lds_g) {
   const Dims& d = ctx->d;
   hipLaunchKernelGGL(bwd_init, dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p);
   for (int64_t t = d.T - 1; t >= 0; --t) {
     prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE);
-    hipLaunchKernelGGL((bwd_assemble<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BS), lds_a, ctx->stream, p, t);
+    if constexpr (FAST)
+      hipLaunchKernelGGL((bwd_assemble_fast<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BSF), lds_a, ctx->stream, p, t);
+    else
+      hipLaunchKernelGGL((bwd_assemble<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BS), lds_a, ctx->stream, p, t);
     prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE);
     prof_begin(ctx, DDP_HIP_K_BWD_GAINS);
-    hipLaunchKernelGGL((bwd_gains<NC, MC>), dim3((unsigned)d.batch), dim3(BS), lds_g, ctx->stream, p, t);
+    if constexpr (FAST)
+      hipLaunchKernelGGL((bwd_gains_fast<NC, MC>), dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p, t);
+    else
+      hipLaunchKernelGGL((bwd_gains<NC, MC>), dim3((unsigned)d.batch), dim3(BS), lds_g, ctx->stream, p, t);
     prof_end(ctx, DDP_HIP_K_BWD_GAINS);
   }
   HIP_TRY(hipGetLastError());
@@ -477,9 +486,11 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
   bool any_restart = false;
   int rc = DDP_HIP_OK;
   for (int64_t attempt = 0;; ++attempt) {
-    if (d.n == 76 && d.m == 38) rc = launch_sweep<76, 38>(ctx, p, lds_a, lds_g);
-    else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6>(ctx, p, lds_a, lds_g);
-    else rc = launch_sweep<0, 0>(ctx, p, lds_a, lds_g);
+    const bool generic = getenv("DDP_HIP_GENERIC_BWD") != nullptr;   // A/B switch for development
+    if (d.n == 76 && d.m == 38 && !generic) rc = launch_sweep<76, 38, true>(ctx, p, lds_a, lds_g);
+    else if (d.n == 76 && d.m == 38) rc = launch_sweep<76, 38, false>(ctx, p, lds_a, lds_g);
+    else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6, false>(ctx, p, lds_a, lds_g);
+    else rc = launch_sweep<0, 0, false>(ctx, p, lds_a, lds_g);
     if (rc != DDP_HIP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(status.data(), ctx->status_d, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
