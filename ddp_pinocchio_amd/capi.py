@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddp_hip.so")
+LIB_PATH = os.environ.get("DDP_HIP_LIB", os.path.join(_HERE, "libddp_hip.so"))   # override: development A/B builds
 
 MAX_JOINTS = 64
 

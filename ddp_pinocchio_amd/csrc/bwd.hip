@@ -444,6 +444,8 @@ int bwd_setup(ddp_hip_ctx* ctx) {
   int64_t upj = (units + want - 1) / want;
   int64_t cbx = upj / 3; if (cbx < 1) cbx = 1; if (cbx > 8) cbx = 8;
   int64_t cbu = upj;     if (cbu < 1) cbu = 1; if (cbu > 16) cbu = 16;
+  if (const char* ev = getenv("DDP_HIP_BWD_CBX")) { int v = atoi(ev); if (v >= 1 && v <= 8) cbx = v; }    // tuning knobs
+  if (const char* ev = getenv("DDP_HIP_BWD_CBU")) { int v = atoi(ev); if (v >= 1 && v <= 16) cbu = v; }
   ctx->cbx = (int32_t)cbx; ctx->cbu = (int32_t)cbu;
   std::vector<BwdJob> jobs;
   for (int64_t c = 0; c < n; c += cbx) jobs.push_back(BwdJob{0, (int32_t)c, (int32_t)((n - c) < cbx ? (n - c) : cbx), 0});

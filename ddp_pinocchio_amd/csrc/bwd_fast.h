@@ -12,6 +12,15 @@
 //   the column loop, then a column-oriented back substitution -- every phase uses all 256 lanes.
 #pragma once
 
+#ifndef BWD_NT
+#define BWD_NT true
+#endif
+#ifndef BWD_EXP_SKIP_DENSE
+#define BWD_EXP_SKIP_DENSE 0
+#endif
+#ifndef BWD_WAVES_PER_SIMD
+#define BWD_WAVES_PER_SIMD 4
+#endif
 constexpr int BSF = 512;   // workgroup size of the streaming kernel: one N x N slab = 5.6 loads per lane
 
 template <int O, int L>
@@ -57,7 +66,7 @@ __device__ __forceinline__ void slab_finish(const f64x2 (&buf)[SlabShape<O, L>::
 }
 
 template <int N, int M>
-__global__ __launch_bounds__(BSF, 4) void bwd_assemble_fast(BwdParams p, int64_t t) {
+__global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_assemble_fast(BwdParams p, int64_t t) {
   // XCD-aware placement: blocks b and b+8 share an XCD (and its L2); keep all jobs of one instance on one
   // XCD so that its f_x, f_u, V_xx are fetched into a single L2.  Speed only, never correctness.
   int b, jb;
@@ -107,20 +116,20 @@ __global__ __launch_bounds__(BSF, 4) void bwd_assemble_fast(BwdParams p, int64_t
   double* s_part = s_out + (n + m) * cn;       // (n/2+1) * n
   double* s_tmp = s_part + (n / 2 + 1) * n;    // emax
 
-  f64x2 bufN[SlabShape<N, N>::R];
-  f64x2 bufM[SlabShape<N, M>::R];
-  f64x2 bufM2[SlabShape<N, M>::R];
-
+  // V_x and this job's columns of F = f_x (x-job) or f_u (u-job) to LDS (s_part is free until the first slab)
+  const double* Fc = (kind == 0 ? fx : fu) + c0 * n;
+  double* s_F = s_part;
   for (int i = tid; i < n; i += BSF) s_v[i] = Vx[i];
   for (int i = tid; i < e; i += BSF) s_tmp[i] = pe[i] + mu * eqv[i];   // ddp_bwd.ipp:46
+  for (int idx = tid; idx < n * cn; idx += BSF) s_F[idx] = Fc[idx];
+  __syncthreads();
 
-  // W = V_xx * F(:, c0:c0+cn)
-  const double* Fc = (kind == 0 ? fx : fu) + c0 * n;
+  // W = V_xx * F(:, c0:c0+cn): one lane per entry, 76 independent (coalesced) loads, 19 in flight
   for (int idx = tid; idx < n * cn; idx += BSF) {
     const int r = idx % n, c = idx / n;
-    const double* fc = Fc + c * n;
+    const double* fc = s_F + c * n;
     double s = 0.0;
-#pragma unroll 4
+#pragma unroll 19
     for (int l = 0; l < n; ++l) s += Vxx[r + l * n] * fc[l];
     s_W[idx] = s;
   }
@@ -133,11 +142,38 @@ __global__ __launch_bounds__(BSF, 4) void bwd_assemble_fast(BwdParams p, int64_t
     else acc = p.luu[bt * m * m + r + col * m];
     s_out[idx] = acc;
   }
-  // first slabs in flight (issued after the W loop: keeping them live across it only made the compiler spill)
-  if (kind == 0) { slab_issue<N, N, false>(fx, bufN); slab_issue<N, M, false>(fu, bufM); }
-  else { slab_issue<N, M, false>(fu, bufM); }
-  __syncthreads();
-
+  // Q_x / Q_u entries of this job's columns (:61-68): one wave per column, lanes across the rows of F
+  for (int c = tid >> 6; c < cn; c += BSF >> 6) {
+    const int col = c0 + c;
+    const int lane = tid & 63;
+    double s = 0.0;
+    if (lane < n / 2) {
+      const f64x2 a = *reinterpret_cast<const f64x2*>(s_F + c * n + 2 * lane);
+      const f64x2 vv = *reinterpret_cast<const f64x2*>(s_v + 2 * lane);
+      s = a.x * vv.x + a.y * vv.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+      double acc;
+      if (kind == 0) {
+        acc = p.lx[bt * n + col];
+        acc += s;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < e; ++i) { s1 += eqx[i + col * e] * s_tmp[i]; s2 += pex[i + col * e] * eqv[i]; }
+        acc += s1;
+        acc += s2;
+        Qx[col] = acc;
+      } else {
+        acc = p.lu[bt * m + col];
+        acc += s;
+        double s1 = 0.0;
+        for (int i = 0; i < e; ++i) s1 += equ[i + col * e] * s_tmp[i];
+        acc += s1;
+        Qu[col] = acc;
+      }
+    }
+  }
   const bool tens = p.has_tensors != 0;
 
   // multiplier terms (:72-74, :79-80, :85-86), added between the dense and the tensor terms as the
@@ -185,78 +221,84 @@ __global__ __launch_bounds__(BSF, 4) void bwd_assemble_fast(BwdParams p, int64_t
     __syncthreads();
   };
 
-  // Q_x / Q_u entries of this job's columns (:61-68)
-  for (int c = tid; c < cn; c += BSF) {
-    const int col = c0 + c;
-    double acc, s = 0.0;
+  // Everything that remains is a sequence of identical "units": a 76 x 38 column-major block (one f_u /
+  // f_ux / f_uu slab, or half of an f_x / f_xx slab) contracted with a vector.  Units 0 .. UD-1 are the dense
+  // products f^T w_c (:71, :78, :84), units UD .. 2 UD-1 the V_x-contracted tensor slabs (:75, :81, :87) --
+  // the HBM stream.  Four register buffers rotate, so three units (69 KB) per workgroup are always in
+  // flight behind the one being reduced; the LDS partials are double buffered: one barrier per unit.
+  constexpr int UPC = 3;                                  // units per x-column: f_x lo, f_x hi, f_u
+  const int upc = kind == 0 ? UPC : 1;
+  const int UD = upc * cn;
+  const int U = tens ? 2 * UD : UD;
+  const double* Txx = p.fxx + (bt * n + c0) * (int64_t)n * n;   // f_xx(:,:,c0 + c): n x n slabs, contiguous in c
+  const double* Tux = p.fux + (bt * n + c0) * (int64_t)n * m;   // f_ux(:,:,c0 + c): n x m slabs
+  const double* Tuu = p.fuu + (bt * m + c0) * (int64_t)n * m;   // f_uu(:,:,c0 + c): n x m slabs
+  auto unit_ptr = [&](int u) -> const double* {
+    const bool dense = u < UD;
+    const int d = dense ? u : u - UD;
+    const int c = d / upc, part = d - c * upc;
     if (kind == 0) {
-      acc = p.lx[bt * n + col];
-#pragma unroll 2
-      for (int l = 0; l < n; ++l) s += fx[l + col * n] * s_v[l];
-      acc += s;
-      double s1 = 0.0, s2 = 0.0;
-      for (int i = 0; i < e; ++i) { s1 += eqx[i + col * e] * s_tmp[i]; s2 += pex[i + col * e] * eqv[i]; }
-      acc += s1;
-      acc += s2;
-      Qx[col] = acc;
-    } else {
-      acc = p.lu[bt * m + col];
-#pragma unroll 2
-      for (int l = 0; l < n; ++l) s += fu[l + col * n] * s_v[l];
-      acc += s;
-      double s1 = 0.0;
-      for (int i = 0; i < e; ++i) s1 += equ[i + col * e] * s_tmp[i];
-      acc += s1;
-      Qu[col] = acc;
+      if (dense) return part < 2 ? fx + part * (M * n) : fu;
+      return part < 2 ? Txx + (int64_t)c * n * n + part * (M * n) : Tux + (int64_t)c * n * m;
     }
-  }
+    return dense ? fu : Tuu + (int64_t)c * n * m;
+  };
+  auto unit_vec = [&](int u) -> const double* { return u < UD ? s_W + ((u) / upc) * n : s_v; };
+  auto unit_out = [&](int u) -> double* {
+    const int d = u < UD ? u : u - UD;
+    const int c = d / upc, part = d - c * upc;
+    return s_out + c * rows + part * M;
+  };
+  using US = SlabShape<N, M>;
+  f64x2 buf0[US::R], buf1[US::R], buf2[US::R], buf3[US::R];
+  double* s_p0 = s_part;
+  double* s_p1 = s_part + US::LD * M;
+#define UNIT_ISSUE(BUF, u)                                                                  \
+  do {                                                                                      \
+    if ((u) < U) {                                                                          \
+      if ((u) < UD) slab_issue<N, M, false>(unit_ptr(u), BUF);                              \
+      else slab_issue<N, M, BWD_NT>(unit_ptr(u), BUF);                                      \
+    }                                                                                       \
+  } while (0)
+#define UNIT_STEP(BUF, u)                                                                   \
+  do {                                                                                      \
+    if ((u) < U) {                                                                          \
+      if ((u) == UD && e > 0) { __syncthreads(); add_eq_terms(); }                          \
+      double* sp = ((u) & 1) ? s_p1 : s_p0;                                                 \
+      const double* vec = unit_vec(u);                                                      \
+      _Pragma("unroll") for (int r = 0; r < US::R; ++r) {                                   \
+        const int f = tid + r * BSF;                                                        \
+        if (r < US::R - 1 || f < US::TOTAL) {                                               \
+          const int j = f / US::HP;                                                         \
+          const int ip = f - j * US::HP;                                                    \
+          const f64x2 vv = *reinterpret_cast<const f64x2*>(vec + 2 * ip);                   \
+          sp[j * US::LD + ip] = vv.x * BUF[r].x + vv.y * BUF[r].y;                          \
+        }                                                                                   \
+      }                                                                                     \
+      __syncthreads();                                                                      \
+      if (tid < M) {                                                                        \
+        const double* pj = sp + tid * US::LD;                                               \
+        double sacc = 0.0;                                                                  \
+        _Pragma("unroll") for (int k = 0; k < US::HP; ++k) sacc += pj[k];                   \
+        unit_out(u)[tid] += sacc;                                                           \
+      }                                                                                     \
+      UNIT_ISSUE(BUF, (u) + 4);                                                             \
+    }                                                                                       \
+  } while (0)
 
-  if (kind == 0) {
-    const double* Txx = p.fxx + (bt * n + c0) * (int64_t)n * n;   // f_xx(:,:,c0 ...): n x n slabs, contiguous in c
-    const double* Tux = p.fux + (bt * n + c0) * (int64_t)n * m;   // f_ux(:,:,c0 ...): n x m slabs
-    for (int c = 0; c < cn; ++c) {                                 // f^T V_xx f  (:71, :84)
-      slab_finish<N, N>(bufN, s_W + c * n, s_part, s_out + c * rows);
-      if (c + 1 < cn) slab_issue<N, N, false>(fx, bufN);
-      else if (tens) slab_issue<N, N, true>(Txx, bufN);
-      slab_finish<N, M>(bufM, s_W + c * n, s_part, s_out + c * rows + n);
-      if (c + 1 < cn) slab_issue<N, M, false>(fu, bufM);
-      else if (tens) slab_issue<N, M, true>(Tux, bufM);
-    }
-    add_eq_terms();
-    if (tens) {                                                    // V_x-contracted tensors (:75, :87): the HBM stream
-      for (int c = 0; c < cn; ++c) {
-        slab_finish<N, N>(bufN, s_v, s_part, s_out + c * rows);
-        if (c + 1 < cn) slab_issue<N, N, true>(Txx + (int64_t)(c + 1) * n * n, bufN);
-        slab_finish<N, M>(bufM, s_v, s_part, s_out + c * rows + n);
-        if (c + 1 < cn) slab_issue<N, M, true>(Tux + (int64_t)(c + 1) * n * m, bufM);
-      }
-    }
-  } else {
-    // u-columns: slab k < cn is f_u against w_k (:78), slab cn + c is f_uu(:,:,c0+c) against V_x (:81);
-    // slab k lives in bufM (k even) or bufM2 (k odd), slab k+2 is issued as soon as slab k is reduced
-    const double* Tuu = p.fuu + (bt * m + c0) * (int64_t)n * m;
-    const int K = tens ? 2 * cn : cn;
-    if (K > 1) {
-      if (cn > 1) slab_issue<N, M, false>(fu, bufM2);
-      else slab_issue<N, M, true>(Tuu, bufM2);
-    }
-    for (int k = 0; k < K; ++k) {
-      if (k == cn) add_eq_terms();
-      const double* vec = k < cn ? s_W + k * n : s_v;
-      double* out = s_out + (k < cn ? k : k - cn) * rows;
-      const int k2 = k + 2;
-      if ((k & 1) == 0) {
-        slab_finish<N, M>(bufM, vec, s_part, out);
-        if (k2 < cn) slab_issue<N, M, false>(fu, bufM);
-        else if (k2 < K) slab_issue<N, M, true>(Tuu + (int64_t)(k2 - cn) * n * m, bufM);
-      } else {
-        slab_finish<N, M>(bufM2, vec, s_part, out);
-        if (k2 < cn) slab_issue<N, M, false>(fu, bufM2);
-        else if (k2 < K) slab_issue<N, M, true>(Tuu + (int64_t)(k2 - cn) * n * m, bufM2);
-      }
-    }
-    if (K == cn) add_eq_terms();
+  { const int u0 = BWD_EXP_SKIP_DENSE ? ((UD + 3) & ~3) : 0;
+    UNIT_ISSUE(buf0, u0); UNIT_ISSUE(buf1, u0 + 1); UNIT_ISSUE(buf2, u0 + 2); UNIT_ISSUE(buf3, u0 + 3); }
+  __syncthreads();   // s_W, s_out (l terms) and s_F readers are done: s_part may be overwritten
+  for (int u = BWD_EXP_SKIP_DENSE ? ((UD + 3) & ~3) : 0; u < U; u += 4) {
+    UNIT_STEP(buf0, u);
+    UNIT_STEP(buf1, u + 1);
+    UNIT_STEP(buf2, u + 2);
+    UNIT_STEP(buf3, u + 3);
   }
+  __syncthreads();
+  if (U == UD && e > 0) add_eq_terms();
+#undef UNIT_STEP
+#undef UNIT_ISSUE
 
   for (int idx = tid; idx < rows * cn; idx += BSF) {
     const int r = idx % rows, c = idx / rows;
