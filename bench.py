@@ -136,9 +136,11 @@ def main():
         ms_f, n_f = ctx.profile_get(capi.K_FWD_ROLLOUT)
         ms_l1, n_l1 = ctx.profile_get(capi.K_LIN_FIRST)
         ms_l2, n_l2 = ctx.profile_get(capi.K_LIN_SECOND)
-        # algorithmic bytes of ONE bwd_assemble launch = one timestep of every resident instance:
-        # B_bwd / T per instance x S instances
-        bytes_per_launch = ctx.bwd_algorithmic_bytes() / T * S
+        # algorithmic bytes of ONE bwd_contract (K3) launch = one timestep of every resident instance: the three
+        # tensors read once (n^3 + n^2 m + n m^2 doubles) + V_x read + the contracted blocks written
+        n_, m_ = 2 * nv, nv
+        words = (n_ ** 3 + n_ * n_ * m_ + n_ * m_ * m_) + n_ + (n_ * n_ + m_ * n_ + m_ * m_)
+        bytes_per_launch = 8.0 * words * S if full else 0.0
         avg_s = (ms_a / max(n_a, 1)) * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {
@@ -152,11 +154,11 @@ def main():
             "config": {"workload": f"Talos-like 38-DoF tree (nq=nv=38, n=76, m=38), T={T}, {S} seeds/GPU x {a.n_alpha} "
                                    f"line-search alphas, {'full DDP (FD f_x,f_u + FD f_xx,f_ux,f_uu mode 2)' if full else 'tensor-free (Gauss-Newton) variant'}",
                        "mode": a.mode, "horizon": T, "seeds_per_gpu": S, "n_alpha": a.n_alpha, "parallelism": f"seeds x{world}"},
-            "roofline": {"kernel": "bwd_assemble", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "bwd_contract (K3: V_x-contracted f_xx, f_ux, f_uu)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": n_a},
             "phases_ms_per_step": {k: v / a.steps for k, v in phase_ms.items()},
-            "kernels_ms_per_step": {"bwd_assemble": ms_a / a.steps, "bwd_gains": ms_g / a.steps, "fwd_rollout": ms_f / a.steps,
+            "kernels_ms_per_step": {"bwd_contract": ms_a / a.steps, "bwd_riccati": ms_g / a.steps, "fwd_rollout": ms_f / a.steps,
                                     "lin_first": ms_l1 / a.steps, "lin_second": ms_l2 / a.steps},
         }
         if not a.no_cpu_baseline:

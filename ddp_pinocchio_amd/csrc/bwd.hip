@@ -29,7 +29,7 @@ struct BwdParams {
   const double *eq_val, *eq_x, *eq_u, *eq_xx, *eq_ux, *eq_uu;
   const double *x, *mult_val, *mult_jac;
   double *fb_origin, *fb_val, *fb_jac, *vx_trace, *vxx_trace;
-  double *ws_V, *ws_Q, *reg, *mu;
+  double *ws_V, *ws_Q, *ws_D, *reg, *mu;
   int32_t* status;
   int64_t* restarts;
   const BwdJob* jobs;
@@ -365,6 +365,7 @@ __global__ __launch_bounds__(BS) void bwd_gains(BwdParams p, int64_t t) {
 }
 
 #include "bwd_fast.h"
+#include "bwd_split.h"
 
 size_t assemble_lds_bytes(const ddp_hip_ctx* ctx, int cn_max) {
   const Dims& d = ctx->d;
@@ -394,7 +395,7 @@ BwdParams make_params(ddp_hip_ctx* ctx) {
   p.mult_val = S(DDP_HIP_SEQ_MULT_VAL); p.mult_jac = S(DDP_HIP_SEQ_MULT_JAC);
   p.fb_origin = S(DDP_HIP_SEQ_FB_ORIGIN); p.fb_val = S(DDP_HIP_SEQ_FB_VAL); p.fb_jac = S(DDP_HIP_SEQ_FB_JAC);
   p.vx_trace = S(DDP_HIP_SEQ_VX_TRACE); p.vxx_trace = S(DDP_HIP_SEQ_VXX_TRACE);
-  p.ws_V = ctx->ws_V; p.ws_Q = ctx->ws_Q; p.reg = ctx->reg_d; p.mu = ctx->mu_d;
+  p.ws_V = ctx->ws_V; p.ws_Q = ctx->ws_Q; p.ws_D = ctx->ws_D; p.reg = ctx->reg_d; p.mu = ctx->mu_d;
   p.status = ctx->status_d; p.restarts = ctx->restarts_d;
   p.jobs = ctx->jobs_d;
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
@@ -423,6 +424,35 @@ int launch_sweep(ddp_hip_ctx* ctx, const BwdParams& p, size_t lds_a, size_t lds_
   return DDP_HIP_OK;
 }
 
+// split path (compile-time shapes): K3 bwd_contract streams the tensors, K4 bwd_riccati does the rest
+template <int NC, int MC>
+int launch_sweep_split(ddp_hip_ctx* ctx, const BwdParams& p) {
+  const Dims& d = ctx->d;
+  const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
+  const size_t lds_c = sizeof(double) * (size_t)(NC + (NC + MC) * cn_max + 2 * (NC / 2 + 1) * MC);
+  const size_t lds_r = sizeof(double) * (size_t)(2 * NC * (NC + MC));
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_riccati<NC, MC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense0<NC, MC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(bwd_init, dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p);
+  hipLaunchKernelGGL((bwd_dense0<NC, MC>), dim3((unsigned)d.batch), dim3(BSR), lds_r, ctx->stream, p);
+  for (int64_t t = d.T - 1; t >= 0; --t) {
+    if (p.has_tensors) {
+      prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE);
+      hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BSF), lds_c, ctx->stream, p, t);
+      prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE);
+    }
+    prof_begin(ctx, DDP_HIP_K_BWD_GAINS);
+    hipLaunchKernelGGL((bwd_riccati<NC, MC>), dim3((unsigned)d.batch), dim3(BSR), lds_r, ctx->stream, p, t);
+    prof_end(ctx, DDP_HIP_K_BWD_GAINS);
+  }
+  HIP_TRY(hipGetLastError());
+  return DDP_HIP_OK;
+}
+
 }  // namespace
 
 int bwd_setup(ddp_hip_ctx* ctx) {
@@ -430,6 +460,7 @@ int bwd_setup(ddp_hip_ctx* ctx) {
   const int64_t n = d.n, m = d.m, B = d.batch;
   HIP_TRY(hipMalloc(&ctx->ws_V, sizeof(double) * (size_t)(B * (n + n * n))));
   HIP_TRY(hipMalloc(&ctx->ws_Q, sizeof(double) * (size_t)(B * (n + m + n * n + m * n + m * m))));
+  HIP_TRY(hipMalloc(&ctx->ws_D, sizeof(double) * (size_t)(B * (n * n + m * n + m * m))));
   HIP_TRY(hipMalloc(&ctx->reg_d, sizeof(double) * (size_t)B));
   HIP_TRY(hipMalloc(&ctx->mu_d, sizeof(double) * (size_t)B));
   HIP_TRY(hipMalloc(&ctx->status_d, sizeof(int32_t) * (size_t)B));
@@ -459,6 +490,7 @@ int bwd_setup(ddp_hip_ctx* ctx) {
 void bwd_teardown(ddp_hip_ctx* ctx) {
   if (ctx->ws_V) (void)hipFree(ctx->ws_V);
   if (ctx->ws_Q) (void)hipFree(ctx->ws_Q);
+  if (ctx->ws_D) (void)hipFree(ctx->ws_D);
   if (ctx->reg_d) (void)hipFree(ctx->reg_d);
   if (ctx->mu_d) (void)hipFree(ctx->mu_d);
   if (ctx->status_d) (void)hipFree(ctx->status_d);
@@ -489,7 +521,9 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
   int rc = DDP_HIP_OK;
   for (int64_t attempt = 0;; ++attempt) {
     const bool generic = getenv("DDP_HIP_GENERIC_BWD") != nullptr;   // A/B switch for development
-    if (d.n == 76 && d.m == 38 && !generic) rc = launch_sweep<76, 38, true>(ctx, p, lds_a, lds_g);
+    const bool fused = getenv("DDP_HIP_FUSED_BWD") != nullptr;     // previous structure (dense terms inside the streaming kernel)
+    if (d.n == 76 && d.m == 38 && !generic && !fused) rc = launch_sweep_split<76, 38>(ctx, p);
+    else if (d.n == 76 && d.m == 38 && !generic) rc = launch_sweep<76, 38, true>(ctx, p, lds_a, lds_g);
     else if (d.n == 76 && d.m == 38) rc = launch_sweep<76, 38, false>(ctx, p, lds_a, lds_g);
     else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6, false>(ctx, p, lds_a, lds_g);
     else rc = launch_sweep<0, 0, false>(ctx, p, lds_a, lds_g);

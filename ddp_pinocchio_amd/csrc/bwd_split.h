@@ -1,0 +1,506 @@
+// bwd_split.h -- the backward step as the two kernels of SURVEY.md's kernel map (included by bwd.hip):
+//
+//   K3  bwd_contract<N, M>   grid (jobs, batch).  Pure HBM stream: C(j,k) = sum_i V_x,i T(i,j,k) for the three
+//       second-order tensors of one timestep (tensor.hpp:179-198 as called at ddp_bwd.ipp:75,81,87).
+//       Reads every tensor byte exactly once with 16-byte coalesced loads, three 69 KB units per workgroup
+//       always in flight; 0.25 flop/byte.
+//   K4  bwd_riccati<N, M>    grid (batch).  Everything else of the step, LDS / register resident:
+//       Q = l + f^T V_xx f + multiplier terms + C (ddp_bwd.ipp:61-87, in the reference's order of terms),
+//       LLT (:104-105), gains (:134-136), V update (:142-146), and -- while the new V_xx is still in LDS --
+//       the dense product D = [f_x f_u]^T V_xx [f_x f_u] of the NEXT step to be processed (t-1).
+#pragma once
+
+constexpr int BSR = 512;   // workgroup size of K4
+
+template <int N, int M>
+__global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParams p, int64_t t) {
+  // XCD-aware placement: blocks b and b+8 share an XCD; keep the jobs of one instance on one XCD (speed only)
+  int b, jb;
+  {
+    const int njobs = (int)gridDim.x, B = (int)gridDim.y;
+    const int lin = blockIdx.y * njobs + blockIdx.x;
+    if ((B & 7) == 0) {
+      const int xcd = lin & 7, k = lin >> 3;
+      b = xcd + 8 * (k / njobs);
+      jb = k % njobs;
+    } else { b = blockIdx.y; jb = blockIdx.x; }
+  }
+  if (p.status[b] != 0) return;
+  const BwdJob job = p.jobs[jb];
+  constexpr int n = N, m = M;
+  const int64_t T = p.d.T;
+  const int tid = threadIdx.x;
+  const int kind = job.kind, c0 = job.c0, cn = job.cn;
+  const int rows = kind == 0 ? n + m : m;
+  const int64_t bt = (int64_t)b * T + t;
+
+  const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
+  double* C = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m) + n + m;
+  double* Cxx = C;
+  double* Cux = Cxx + n * n;
+  double* Cuu = Cux + m * n;
+
+  using US = SlabShape<N, M>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_v = smem;                          // n
+  double* s_out = s_v + n;                     // rows * cn
+  double* s_p0 = s_out + (n + m) * cn;         // US::LD * M
+  double* s_p1 = s_p0 + US::LD * M;
+
+  // units: 76 x 38 column-major blocks; an x-column is f_xx(:,0:38,c), f_xx(:,38:76,c), f_ux(:,:,c); a u-column f_uu(:,:,c)
+  const int upc = kind == 0 ? 3 : 1;
+  const int U = upc * cn;
+  const double* Txx = p.fxx + (bt * n + c0) * (int64_t)n * n;
+  const double* Tux = p.fux + (bt * n + c0) * (int64_t)n * m;
+  const double* Tuu = p.fuu + (bt * m + c0) * (int64_t)n * m;
+  auto unit_ptr = [&](int u) -> const double* {
+    const int c = u / upc, part = u - c * upc;
+    if (kind == 0) return part < 2 ? Txx + (int64_t)c * n * n + part * (M * n) : Tux + (int64_t)c * n * m;
+    return Tuu + (int64_t)c * n * m;
+  };
+  f64x2 buf0[US::R], buf1[US::R], buf2[US::R], buf3[US::R];
+#define C_ISSUE(BUF, u) do { if ((u) < U) slab_issue<N, M, BWD_NT>(unit_ptr(u), BUF); } while (0)
+  C_ISSUE(buf0, 0); C_ISSUE(buf1, 1); C_ISSUE(buf2, 2); C_ISSUE(buf3, 3);
+
+  for (int i = tid; i < n; i += BSF) s_v[i] = Vx[i];
+  for (int i = tid; i < rows * cn; i += BSF) s_out[i] = 0.0;
+  __syncthreads();
+
+#define C_STEP(BUF, u)                                                                      \
+  do {                                                                                      \
+    if ((u) < U) {                                                                          \
+      double* sp = ((u) & 1) ? s_p1 : s_p0;                                                 \
+      _Pragma("unroll") for (int r = 0; r < US::R; ++r) {                                   \
+        const int f = tid + r * BSF;                                                        \
+        if (r < US::R - 1 || f < US::TOTAL) {                                               \
+          const int j = f / US::HP;                                                         \
+          const int ip = f - j * US::HP;                                                    \
+          const f64x2 vv = *reinterpret_cast<const f64x2*>(s_v + 2 * ip);                   \
+          sp[j * US::LD + ip] = vv.x * BUF[r].x + vv.y * BUF[r].y;                          \
+        }                                                                                   \
+      }                                                                                     \
+      __syncthreads();                                                                      \
+      if (tid < M) {                                                                        \
+        const double* pj = sp + tid * US::LD;                                               \
+        double sacc = 0.0;                                                                  \
+        _Pragma("unroll") for (int k = 0; k < US::HP; ++k) sacc += pj[k];                   \
+        const int c_ = (u) / upc, part_ = (u) - c_ * upc;                                   \
+        s_out[c_ * rows + part_ * M + tid] = sacc;                                          \
+      }                                                                                     \
+      C_ISSUE(BUF, (u) + 4);                                                                \
+    }                                                                                       \
+  } while (0)
+  for (int u = 0; u < U; u += 4) {
+    C_STEP(buf0, u);
+    C_STEP(buf1, u + 1);
+    C_STEP(buf2, u + 2);
+    C_STEP(buf3, u + 3);
+  }
+  __syncthreads();
+#undef C_STEP
+#undef C_ISSUE
+  for (int idx = tid; idx < rows * cn; idx += BSF) {
+    const int r = idx % rows, c = idx / rows;
+    const int col = c0 + c;
+    if (kind == 0) {
+      if (r < n) Cxx[r + col * n] = s_out[idx];
+      else Cux[(r - n) + col * m] = s_out[idx];
+    } else {
+      Cuu[r + col * m] = s_out[idx];
+    }
+  }
+}
+
+// D = [f_x f_u]^T V_xx [f_x f_u] (blocks xx, ux, uu) for timestep td, with V_xx already in s_VW[0 .. N*N).
+// LDS: s_VW (N*(N+M) doubles, V_xx then W = V_xx F), s_F (N*(N+M) doubles).  All BSR lanes take part.
+template <int N, int M>
+__device__ __forceinline__ void dense_product(const BwdParams& p, int b, int64_t td, double* s_VW, double* s_F) {
+  constexpr int n = N, m = M, NM = N + M;
+  const int tid = threadIdx.x;
+  const int64_t bt = (int64_t)b * p.d.T + td;
+  const double* fx = p.fx + bt * n * n;
+  const double* fu = p.fu + bt * n * m;
+  double* D = p.ws_D + (int64_t)b * (n * n + m * n + m * m);
+  double* Dxx = D;
+  double* Dux = Dxx + n * n;
+  double* Duu = Dux + m * n;
+  // F = [f_x | f_u], column-major, leading dimension N
+  {
+    const f64x2* a = reinterpret_cast<const f64x2*>(fx);
+    const f64x2* c = reinterpret_cast<const f64x2*>(fu);
+    f64x2* d = reinterpret_cast<f64x2*>(s_F);
+    for (int i = tid; i < n * n / 2; i += BSR) d[i] = a[i];
+    for (int i = tid; i < n * m / 2; i += BSR) d[n * n / 2 + i] = c[i];
+  }
+  __syncthreads();
+  // W = V_xx F: 2 x 2 register tiles, two l per step (16-byte LDS reads)
+  constexpr int TR = N / 2, TC = NM / 2, NT_W = TR * TC;          // 38 x 57 tiles
+  constexpr int WI = (NT_W + BSR - 1) / BSR;                      // 5
+  double w[WI][4];
+#pragma unroll
+  for (int it = 0; it < WI; ++it) {
+    const int tile = tid + it * BSR;
+    const int tr = tile % TR, tc = (tile / TR) < TC ? tile / TR : TC - 1;
+    const double* vp = s_VW + 2 * tr;
+    const double* f0 = s_F + (2 * tc) * n;
+    const double* f1 = f0 + n;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll 2
+    for (int l = 0; l < n; l += 2) {
+      const f64x2 v0 = *reinterpret_cast<const f64x2*>(vp + l * n);        // V(r0:r0+2, l)
+      const f64x2 v1 = *reinterpret_cast<const f64x2*>(vp + (l + 1) * n);  // V(r0:r0+2, l+1)
+      const f64x2 g0 = *reinterpret_cast<const f64x2*>(f0 + l);            // F(l:l+2, c0)
+      const f64x2 g1 = *reinterpret_cast<const f64x2*>(f1 + l);            // F(l:l+2, c0+1)
+      a00 += v0.x * g0.x; a00 += v1.x * g0.y;
+      a10 += v0.y * g0.x; a10 += v1.y * g0.y;
+      a01 += v0.x * g1.x; a01 += v1.x * g1.y;
+      a11 += v0.y * g1.x; a11 += v1.y * g1.y;
+    }
+    w[it][0] = a00; w[it][1] = a10; w[it][2] = a01; w[it][3] = a11;
+  }
+  __syncthreads();   // every lane is done reading V_xx: W may overwrite it
+#pragma unroll
+  for (int it = 0; it < WI; ++it) {
+    const int tile = tid + it * BSR;
+    if (tile < NT_W) {
+      const int tr = tile % TR, tc = tile / TR;
+      double* dst = s_VW + 2 * tr + (2 * tc) * n;
+      dst[0] = w[it][0]; dst[1] = w[it][1]; dst[n] = w[it][2]; dst[n + 1] = w[it][3];
+    }
+  }
+  __syncthreads();
+  // D(j, c) = sum_k F(k, j) W(k, c) for the blocks xx (j<N, c<N), ux (j>=N, c<N), uu (j>=N, c>=N); 2 x 2 tiles
+  constexpr int TXX = (N / 2) * (N / 2), TUX = (M / 2) * (N / 2), TUU = (M / 2) * (M / 2), NT_D = TXX + TUX + TUU;
+  for (int tile = tid; tile < NT_D; tile += BSR) {
+    int j0, cc0;
+    if (tile < TXX) { j0 = 2 * (tile % (N / 2)); cc0 = 2 * (tile / (N / 2)); }
+    else if (tile < TXX + TUX) { const int q = tile - TXX; j0 = N + 2 * (q % (M / 2)); cc0 = 2 * (q / (M / 2)); }
+    else { const int q = tile - TXX - TUX; j0 = N + 2 * (q % (M / 2)); cc0 = N + 2 * (q / (M / 2)); }
+    const double* f0 = s_F + j0 * n;
+    const double* f1 = f0 + n;
+    const double* w0 = s_VW + cc0 * n;
+    const double* w1 = w0 + n;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll 2
+    for (int k = 0; k < n; k += 2) {
+      const f64x2 g0 = *reinterpret_cast<const f64x2*>(f0 + k);
+      const f64x2 g1 = *reinterpret_cast<const f64x2*>(f1 + k);
+      const f64x2 h0 = *reinterpret_cast<const f64x2*>(w0 + k);
+      const f64x2 h1 = *reinterpret_cast<const f64x2*>(w1 + k);
+      a00 += g0.x * h0.x; a00 += g0.y * h0.y;
+      a10 += g1.x * h0.x; a10 += g1.y * h0.y;
+      a01 += g0.x * h1.x; a01 += g0.y * h1.y;
+      a11 += g1.x * h1.x; a11 += g1.y * h1.y;
+    }
+    if (j0 < N) {
+      Dxx[j0 + cc0 * n] = a00; Dxx[j0 + 1 + cc0 * n] = a10; Dxx[j0 + (cc0 + 1) * n] = a01; Dxx[j0 + 1 + (cc0 + 1) * n] = a11;
+    } else if (cc0 < N) {
+      const int ju = j0 - N;
+      Dux[ju + cc0 * m] = a00; Dux[ju + 1 + cc0 * m] = a10; Dux[ju + (cc0 + 1) * m] = a01; Dux[ju + 1 + (cc0 + 1) * m] = a11;
+    } else {
+      const int ju = j0 - N, cu = cc0 - N;
+      Duu[ju + cu * m] = a00; Duu[ju + 1 + cu * m] = a10; Duu[ju + (cu + 1) * m] = a01; Duu[ju + 1 + (cu + 1) * m] = a11;
+    }
+  }
+}
+
+// D for the first step to be processed (t = T-1), from V_xx = lfxx (ddp_bwd.ipp:27)
+template <int N, int M>
+__global__ __launch_bounds__(BSR) void bwd_dense0(BwdParams p) {
+  const int b = blockIdx.x;
+  if (p.status[b] != 0) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_VW = smem;
+  double* s_F = smem + N * (N + M);
+  const double* Vxx = p.ws_V + (int64_t)b * (N + N * N) + N;
+  for (int i = threadIdx.x; i < N * N; i += BSR) s_VW[i] = Vxx[i];
+  // (dense_product starts with a barrier after loading F)
+  dense_product<N, M>(p, b, p.d.T - 1, s_VW, s_F);
+}
+
+template <int N, int M>
+__global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
+  const int b = blockIdx.x;
+  if (p.status[b] != 0) return;
+  constexpr int n = N, m = M, nx = N;
+  const int64_t T = p.d.T;
+  const int tid = threadIdx.x;
+  const int64_t bt = (int64_t)b * T + t;
+  const int e = (int)p.ne[t];
+  const int64_t Eo = p.Epre[t], Etot = p.d.Etot;
+  const double mu = p.mu[b];
+  const bool tens = p.has_tensors != 0;
+
+  double* Vx = p.ws_V + (int64_t)b * (n + n * n);
+  double* Vxx = Vx + n;
+  const double* C = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m) + n + m;   // K3's contraction
+  const double* Cxx = C;
+  const double* Cux = Cxx + n * n;
+  const double* Cuu = Cux + m * n;
+  const double* D = p.ws_D + (int64_t)b * (n * n + m * n + m * m);                  // dense f^T V_xx f
+  const double* Dxx = D;
+  const double* Dux = Dxx + n * n;
+  const double* Duu = Dux + m * n;
+  const double* fx = p.fx + bt * n * n;
+  const double* fu = p.fu + bt * n * m;
+  const double* eqv = p.eq_val + (int64_t)b * Etot + Eo;
+  const double* eqx = p.eq_x + ((int64_t)b * Etot + Eo) * n;
+  const double* equ = p.eq_u + ((int64_t)b * Etot + Eo) * m;
+  const double* pe = p.mult_val + (int64_t)b * Etot + Eo;
+  const double* pex = p.mult_jac + ((int64_t)b * Etot + Eo) * n;
+  const double* eq_xx = p.eq_xx + ((int64_t)b * Etot + Eo) * n * n;
+  const double* eq_ux = p.eq_ux + ((int64_t)b * Etot + Eo) * m * n;
+  const double* eq_uu = p.eq_uu + ((int64_t)b * Etot + Eo) * m * m;
+
+  constexpr int lda = M | 1, ldr = M | 1, NR = N + 1, NM = N + M;
+  constexpr int RS = 3, RQ = (M + RS - 1) / RS;
+  constexpr int TJ = 6, AQ = (M + TJ - 1) / TJ;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_VW = smem;                         // N*NM: new V_xx, later W (dense tail)
+  double* s_F = smem + N * NM;                 // N*NM: F of step t-1 (dense tail); before that, the arrays below
+  double* A = s_F;                             // lda*M   Q_uu + reg I -> Cholesky factor (lower)
+  double* R = A + lda * M;                     // ldr*NR  [k | K]
+  double* S = R + ldr * NR;                    // ldr*N   Q_ux
+  double* Y = S + ldr * N;                     // 2*NR    published pivot rows
+  double* s_q = Y + 2 * NR;                    // NM      Q_x | Q_u
+  double* s_vx = s_q + NM;                     // N       incoming V_x
+  double* s_tmp = s_vx + N;                    // emax    pe + mu eq   (ddp_bwd.ipp:46)
+  static_assert(lda * M + ldr * NR + ldr * N + 2 * NR + NM + N + 64 <= N * NM, "phase-A arrays must fit the F region");
+
+  // entries of Q in the reference's order of terms (ddp_bwd.ipp:70-87): l, f^T V_xx f, multiplier terms, multiplier
+  // tensors, V_x-contracted tensors
+  auto q_uu = [&](int i, int j) -> double {
+    double acc = p.luu[bt * m * m + i + j * m];
+    acc += Duu[i + j * m];
+    if (e > 0) {
+      double s1 = 0.0;
+      for (int k = 0; k < e; ++k) s1 += equ[k + i * e] * equ[k + j * e];
+      acc += s1 * mu;                                                          // :79
+      if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_uu[k + (i + j * m) * e]; acc += s3; }   // :80
+    }
+    if (tens) acc += Cuu[i + j * m];                                           // :81
+    return acc;
+  };
+  auto q_ux = [&](int i, int j) -> double {
+    double acc = p.lux[bt * m * n + i + j * m];
+    acc += Dux[i + j * m];
+    if (e > 0) {
+      double s1 = 0.0;
+      for (int k = 0; k < e; ++k) s1 += equ[k + i * e] * (pex[k + j * e] + mu * eqx[k + j * e]);   // :85
+      acc += s1;
+      if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_ux[k + (i + j * m) * e]; acc += s3; }   // :86
+    }
+    if (tens) acc += Cux[i + j * m];                                           // :87
+    return acc;
+  };
+  auto q_xx = [&](int i, int j) -> double {
+    double acc = p.lxx[bt * n * n + i + j * n];
+    acc += Dxx[i + j * n];
+    if (e > 0) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < e; ++k) {
+        s1 += eqx[k + i * e] * (pex[k + j * e] + mu * eqx[k + j * e]);         // :72
+        s2 += pex[k + i * e] * eqx[k + j * e];                                 // :73
+      }
+      acc += s1;
+      acc += s2;
+      if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_xx[k + (i + j * n) * e]; acc += s3; }   // :74
+    }
+    if (tens) acc += Cxx[i + j * n];                                           // :75
+    return acc;
+  };
+
+  for (int i = tid; i < n; i += BSR) s_vx[i] = Vx[i];
+  for (int i = tid; i < e; i += BSR) s_tmp[i] = pe[i] + mu * eqv[i];
+  __syncthreads();
+  // Q_x, Q_u (:61-68): one wave per column of [f_x | f_u]
+  for (int c = tid >> 6; c < NM; c += BSR >> 6) {
+    const int lane = tid & 63;
+    const double* col = c < n ? fx + c * n : fu + (c - n) * n;
+    double s = 0.0;
+    if (lane < n / 2) {
+      const f64x2 a = *reinterpret_cast<const f64x2*>(col + 2 * lane);
+      const f64x2 vv = *reinterpret_cast<const f64x2*>(s_vx + 2 * lane);
+      s = a.x * vv.x + a.y * vv.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+      double acc = c < n ? p.lx[bt * n + c] : p.lu[bt * m + (c - n)];
+      acc += s;
+      if (e > 0) {
+        double s1 = 0.0, s2 = 0.0;
+        if (c < n) { for (int k = 0; k < e; ++k) { s1 += eqx[k + c * e] * s_tmp[k]; s2 += pex[k + c * e] * eqv[k]; } acc += s1; acc += s2; }
+        else { for (int k = 0; k < e; ++k) s1 += equ[k + (c - n) * e] * s_tmp[k]; acc += s1; }
+      }
+      s_q[c] = acc;
+    }
+  }
+  for (int idx = tid; idx < m * n; idx += BSR) S[idx % m + (idx / m) * ldr] = q_ux(idx % m, idx / m);
+  __syncthreads();
+
+  const double reg = p.reg[b];
+  // right-hand sides [-Q_u | -Q_ux] (:135-136) in registers: lane (rc, rs) owns rows rs, rs+3, ... of column rc
+  const int rc = tid % NR, rs = tid / NR;
+  const bool rhs_lane = tid < NR * RS;
+  double r[RQ];
+  if (rhs_lane) {
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int l = rs + RS * q;
+      const int lc = l < m ? l : m - 1;
+      const double v = rc == 0 ? s_q[n + lc] : S[lc + (rc - 1) * ldr];
+      r[q] = l < m ? -v : 0.0;
+    }
+  }
+  // trailing matrix of the factorisation in registers: lane (ti, tj) owns row ti, columns tj, tj+6, ... <= ti
+  const int ti = tid % M, tj = tid / M;
+  const bool a_lane = tj < TJ;
+  double a[AQ];
+#pragma unroll
+  for (int q = 0; q < AQ; ++q) {
+    const int j = tj + TJ * q;
+    a[q] = (a_lane && j <= ti) ? q_uu(ti, j) + (ti == j ? reg : 0.0) : 0.0;           // :104
+  }
+  if (a_lane && tj == 0) A[ti] = a[0];       // raw column 0
+  __syncthreads();
+
+  // Cholesky (lower triangle only; fail <=> pivot <= 0, :105) with the forward substitution fused in (see
+  // bwd_gains_fast); every LDS read is unconditional (clamped index + select)
+  bool failed = false;
+  for (int k = 0; k < m; ++k) {
+    const double piv = A[k + k * lda];
+    if (piv <= 0.0) { failed = true; break; }
+    const double dk = sqrt(piv);
+    if (a_lane && tj == 0 && ti > k) A[ti + k * lda] = A[ti + k * lda] / dk;
+    if (rhs_lane && rs == k % RS) {
+      const int qk = k / RS;
+      double rk = 0.0;
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) rk = q == qk ? r[q] : rk;
+      rk = rk / dk;
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) r[q] = q == qk ? rk : r[q];
+      Y[(k & 1) * NR + rc] = rk;
+    }
+    __syncthreads();
+    const double* Lk = A + k * lda;
+    if (a_lane) {
+      const double lik = Lk[ti];
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) {
+        const int j = tj + TJ * q;
+        const double ljk = Lk[j < m ? j : m - 1];
+        a[q] = (j > k && j <= ti) ? a[q] - lik * ljk : a[q];
+      }
+      const int k1 = k + 1;
+      if (k1 < m && tj == k1 % TJ && ti >= k1) {
+        const int q1 = k1 / TJ;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) v = q == q1 ? a[q] : v;
+        A[ti + k1 * lda] = v;
+      }
+    }
+    if (rhs_lane) {
+      const double yk = Y[(k & 1) * NR + rc];
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        const int l = rs + RS * q;
+        const double llk = Lk[l < m ? l : m - 1];
+        r[q] = (l > k && l < m) ? r[q] - llk * yk : r[q];
+      }
+    }
+    if (tid == k) A[k + k * lda] = dk;
+    __syncthreads();
+  }
+  if (failed) {
+    if (tid == 0) {
+      double rg = p.reg[b], mu2 = p.mu[b];
+      if (rg < mu2) rg = mu2;      // :106-108
+      mu2 *= 2;                    // :109
+      rg *= 2;                     // :110
+      p.reg[b] = rg;
+      p.mu[b] = mu2;
+      p.status[b] = 1;
+      p.restarts[b] += 1;
+    }
+    return;
+  }
+  for (int k = m - 1; k >= 0; --k) {          // back substitution L^T x = y
+    if (rhs_lane && rs == k % RS) {
+      const double dk = A[k + k * lda];
+      const int qk = k / RS;
+      double rk = 0.0;
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) rk = q == qk ? r[q] : rk;
+      rk = rk / dk;
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) r[q] = q == qk ? rk : r[q];
+      Y[(k & 1) * NR + rc] = rk;
+    }
+    __syncthreads();
+    if (rhs_lane) {
+      const double xk = Y[(k & 1) * NR + rc];
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        const int i = rs + RS * q;
+        const double lki = A[k + (i < m ? i : m - 1) * lda];
+        r[q] = i < k ? r[q] - lki * xk : r[q];
+      }
+    }
+  }
+
+  double* fbo = p.fb_origin + bt * nx;
+  const double* xt = p.x + ((int64_t)b * (T + 1) + t) * nx;
+  for (int i = tid; i < nx; i += BSR) fbo[i] = xt[i];                        // :134
+  if (rhs_lane) {
+    double* dst = rc == 0 ? p.fb_val + bt * m : p.fb_jac + bt * m * n + (rc - 1) * m;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int l = rs + RS * q;
+      if (l < m) { dst[l] = r[q]; R[l + rc * ldr] = r[q]; }
+    }
+  }
+  __syncthreads();
+
+  // V_x = Q_x + Q_ux^T k (:142-143);  V_xx = Q_xx + Q_ux^T K (:145-146), 1 x 4 register tiles; the new V_xx also
+  // goes to LDS for the dense product of the next step
+  for (int i = tid; i < n; i += BSR) {
+    double s = 0.0;
+#pragma unroll 2
+    for (int l = 0; l < m; ++l) s += S[l + i * ldr] * R[l];
+    const double v = s_q[i] + s;
+    Vx[i] = v;
+    if (p.vx_trace) p.vx_trace[bt * n + i] = v;
+  }
+  for (int idx = tid; idx < n * (n / 4); idx += BSR) {
+    const int i = idx % n, j0 = (idx / n) * 4;
+    const double* si = S + i * ldr;
+    const double* k0 = R + (j0 + 1) * ldr;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 2
+    for (int l = 0; l < m; ++l) {
+      const double sv = si[l];
+      s0 += sv * k0[l];
+      s1 += sv * k0[l + ldr];
+      s2 += sv * k0[l + 2 * ldr];
+      s3 += sv * k0[l + 3 * ldr];
+    }
+    const double sv4[4] = {s0, s1, s2, s3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = i + (j0 + q) * n;
+      const double v = q_xx(i, j0 + q) + sv4[q];
+      Vxx[o] = v;
+      s_VW[o] = v;
+      if (p.vxx_trace) p.vxx_trace[bt * n * n + o] = v;
+    }
+  }
+  if (t == 0) {
+    if (tid == 0) p.status[b] = 2;                                           // :149-151
+    return;
+  }
+  __syncthreads();   // V_xx complete in LDS; A, R, S, Y are dead: their space becomes F
+  dense_product<N, M>(p, b, t - 1, s_VW, s_F);
+}

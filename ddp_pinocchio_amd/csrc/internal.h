@@ -69,6 +69,7 @@ struct ddp_hip_ctx {
   // backward workspace, per instance
   double* ws_V = nullptr;      // [batch][n + n*n]          V_x | V_xx
   double* ws_Q = nullptr;      // [batch][n + m + n*n + m*n + m*m]   Q_x | Q_u | Q_xx | Q_ux | Q_uu
+  double* ws_D = nullptr;      // [batch][n*n + m*n + m*m]   dense f^T V_xx f of the next step (split kernels)
   double* reg_d = nullptr;     // [batch]
   double* mu_d = nullptr;      // [batch]
   int32_t* status_d = nullptr; // [batch] 0 active, 1 failed this attempt, 2 done
