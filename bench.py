@@ -45,7 +45,7 @@ def main():
     a = parse()
     import torch
     import torch.distributed as dist
-    from ddp_pinocchio_amd import capi
+    from ddp_pinocchio_amd import capi, shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -76,8 +76,6 @@ def main():
 
     reg = np.zeros(S)
     mu = np.full(S, 1e2)
-    best = torch.zeros(1, dtype=torch.float64, device="cuda")
-    besti = torch.zeros(1, dtype=torch.int64, device="cuda")
     phase_ms = {"linearize": 0.0, "backward": 0.0, "forward": 0.0}
 
     def one_iteration(timed):
@@ -93,15 +91,10 @@ def main():
         reg = np.where(reg < 1e-5, 0.0, reg)
         ctx.swap_traj()                                      # ddp.hpp:826
         if world > 1:
-            # best-cost pick over all seeds of all ranks: min cost, then the smallest index attaining it
+            # the one exchange step: best-cost pick over all seeds of all ranks (two 8-byte RCCL all-reduces)
             ctx.cost_seq_aug(0, mu)
             costs = ctx.download("COSTS_OLD").sum(axis=1)
-            j = int(np.argmin(costs))
-            best[0] = float(costs[j])
-            mine = best.clone()
-            dist.all_reduce(best, op=dist.ReduceOp.MIN)
-            besti[0] = rank * S + j if float(mine[0]) == float(best[0]) else np.iinfo(np.int64).max
-            dist.all_reduce(besti, op=dist.ReduceOp.MIN)
+            shard.best_of(costs, [rank * S + s for s in range(S)], device="cuda")
         if timed:
             phase_ms["linearize"] += (t1 - t0) * 1e3
             phase_ms["backward"] += (t2 - t1) * 1e3
