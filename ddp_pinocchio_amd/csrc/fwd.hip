@@ -5,6 +5,8 @@
 // (instance, step-size candidate) chains: one lane per chain, the candidates of one instance in
 // adjacent lanes so that the gain matrices K_t are fetched once per wave.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -164,6 +166,82 @@ __global__ void forward_kernel(FwdParams p) {
   p.fw_dcost[(int64_t)b * na + a] = dsum;
 }
 
+// Latency path of the same rollouts (tree models, no constraints): one 64-lane workgroup per instance, 8 lanes per
+// candidate.  The gain product K_t (x_new - x_old) is spread over the 8 lanes of a candidate (each takes every 8th
+// column of K_t, 16-byte loads of contiguous columns, then three xor-shuffles); the forward dynamics runs on the
+// first lane of each candidate with its per-joint state in LDS instead of scratch.
+template <int NJ>
+__global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
+  constexpr int NC = 8, NH = 8;                      // candidates per instance, helper lanes per candidate
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* aba_state = lds;                           // ABA_LDS_SLOTS * NJ * NC
+  double* s_dx = lds + rbd::ABA_LDS_SLOTS * NJ * NC; // NC * 2 NJ
+  const int b = blockIdx.x;
+  if (p.state[b] != 0) return;
+  const int tid = threadIdx.x, a = tid / NH, h = tid % NH;
+  const int na = p.n_alpha;
+  const int cand = p.round * na + a;
+  const bool live = a < na && cand <= 33;            // 2^-34 < 1e-10: never tried (ddp_fwd.ipp:35-37)
+  if (a < na && cand > 33 && h == 0) p.fw_dcost[(int64_t)b * na + a] = INFINITY;
+  const double step = ldexp(1.0, -cand);
+  const DevModel& m = *p.model;
+  constexpr int n = 2 * NJ, nx = 2 * NJ, nu = NJ;
+  const int64_t T = p.d.T;
+  const double* xo = p.x_old + (int64_t)b * (T + 1) * nx;
+  const double* uo = p.u_old + (int64_t)b * T * nu;
+  double* xw = p.fw_x + ((int64_t)b * na + (a < na ? a : 0)) * (T + 1) * nx;
+  double* uw = p.fw_u + ((int64_t)b * na + (a < na ? a : 0)) * T * nu;
+  const double* cold = p.costs_old + (int64_t)b * (T + 1);
+  double* dx = s_dx + a * n;
+  double x[2 * NJ], xn[2 * NJ], u[NJ];
+  const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
+  if (h == 0 && live)
+    for (int i = 0; i < nx; ++i) { x[i] = x0[i]; xw[i] = x0[i]; }
+  double dsum = 0.0;
+  for (int64_t t = 0; t < T; ++t) {
+    const double* k = p.fb_val + ((int64_t)b * T + t) * nu;
+    const double* K = p.fb_jac + ((int64_t)b * T + t) * nu * n;
+    if (h == 0 && live)
+      for (int i = 0; i < n; ++i) dx[i] = x[i] - xo[t * nx + i];               // :45 difference(out, old, new)
+    __syncthreads();
+    double acc[NJ];
+#pragma unroll
+    for (int i = 0; i < nu; ++i) acc[i] = 0.0;
+    for (int l = h; l < n; l += NH) {
+      const double d = dx[l];
+      const double* Kc = K + (int64_t)l * nu;
+#pragma unroll
+      for (int i = 0; i < nu; ++i) acc[i] += Kc[i] * d;
+    }
+#pragma unroll
+    for (int i = 0; i < nu; ++i) {
+      acc[i] += __shfl_xor(acc[i], 1, 64);
+      acc[i] += __shfl_xor(acc[i], 2, 64);
+      acc[i] += __shfl_xor(acc[i], 4, 64);
+    }
+    if (h == 0 && live) {
+#pragma unroll
+      for (int i = 0; i < nu; ++i) {
+        double ui = uo[t * nu + i] + step * k[i];                               // :47-48
+        ui += acc[i];                                                           // :49
+        u[i] = ui;
+        uw[t * nu + i] = ui;
+      }
+      double un = 0;
+      for (int i = 0; i < nu; ++i) un += u[i] * u[i];
+      const double c_new = 0.5 * m.c * un;                                      // problem_t::l (no constraints on this path)
+      dsum += c_new - cold[t];
+      rbd::eval_f_lds<NJ, NC>(m, x, u, xn, aba_state, a);                       // :50
+      for (int i = 0; i < nx; ++i) { x[i] = xn[i]; xw[(t + 1) * nx + i] = xn[i]; }
+    }
+    __syncthreads();
+  }
+  if (h == 0 && live) {
+    dsum += 0.0 - cold[T];
+    p.fw_dcost[(int64_t)b * na + a] = dsum;
+  }
+}
+
 // accept rule (ddp_fwd.ipp:56-60): the first (= largest) candidate with sum(new - old) <= 0; the winner's
 // trajectory becomes (X_NEW, U_NEW).  grid = batch.
 __global__ void select_kernel(FwdParams p) {
@@ -312,9 +390,22 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
   for (int round = 0; round * n_alpha <= 33; ++round) {
     p.round = round;
     prof_begin(ctx, DDP_HIP_K_FWD_ROLLOUT);
+    // tree models without constraints: the latency path (one workgroup per instance, 8 lanes per candidate)
+    const bool lat_path = ctx->model_h.kind == DDP_HIP_MODEL_TREE && d.Etot == 0 && n_alpha <= 8 && d.nv == 38 &&
+                          getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
+    if (lat_path) {
+      const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * 76);
+      static bool attr = false;
+      if (!attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+      }
+      hipLaunchKernelGGL((forward_kernel_lat<38>), dim3((unsigned)B), dim3(64), lds, ctx->stream, p);
+    } else {
 #define CALL(NJ) hipLaunchKernelGGL((forward_kernel<NJ>), dim3(grid), dim3(bs), 0, ctx->stream, p)
-    DISPATCH_NJ(d.nv, CALL);
+      DISPATCH_NJ(d.nv, CALL);
 #undef CALL
+    }
     prof_end(ctx, DDP_HIP_K_FWD_ROLLOUT);
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, p);
     HIP_TRY(hipGetLastError());

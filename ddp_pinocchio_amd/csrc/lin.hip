@@ -11,6 +11,7 @@
 // are laid out one evaluation per lane.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "internal.h"
 #include "rbd.h"
@@ -28,6 +29,7 @@ struct LinParams {
   double *f_val, *fx, *fu, *fxx, *fux, *fuu;
   double *eq_val, *eq_x, *eq_u, *eq_xx, *eq_ux, *eq_uu;
   int32_t has_tensors;
+  double* qcache;   // [batch*T][nv+1][nv*QC_STRIDE]: q-dependent part of the ABA at the base q and at q + eps e_i (mode 2)
 };
 
 constexpr int LBS = 64;
@@ -113,6 +115,26 @@ __global__ void lin_first_kernel(LinParams p) {
 }
 
 // ---- second order, mode 2 (problem.hpp:152-298) --------------------------------------------------------
+// q-dependent part of the ABA for the nv+1 configurations the mode-2 stencil visits more than once:
+// cfg 0 = q, cfg 1+i = q + eps e_i (eps = eps_mach^(1/4), problem.hpp:188)
+template <int NJ>
+__global__ void lin_qcache_kernel(LinParams p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t T = p.d.T;
+  const DevModel& m = *p.model;
+  const int nv = m.nv, C = nv + 1;
+  if (gid >= p.d.batch * T * C) return;
+  const int cfg = (int)(gid % C);
+  const int64_t bt = gid / C;
+  const int b = (int)(bt / T);
+  const int64_t t = bt % T;
+  double x[2 * NJ], u[NJ];
+  load_xu<NJ>(p, b, t, x, u);
+  const double eps = sqrt(sqrt(DBL_EPSILON));
+  if (cfg > 0) x[cfg - 1] = x[cfg - 1] + eps;
+  rbd::aba_qpart<NJ>(m, x, p.qcache + (bt * C + cfg) * (int64_t)nv * rbd::QC_STRIDE);
+}
+
 // diagonal entries, :192-222
 template <int NJ>
 __global__ void lin_diag_kernel(LinParams p) {
@@ -133,7 +155,12 @@ __global__ void lin_diag_kernel(LinParams p) {
   const bool at_x = i < n;
   const int idx = at_x ? i : i - n;
   if (at_x) x[idx] = x[idx] + eps; else u[idx] = u[idx] + eps;
-  rbd::eval_f<NJ>(m, x, u, f1);
+  if (p.qcache) {
+    const int nv = m.nv, cfg = (at_x && idx < nv) ? 1 + idx : 0;
+    rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
+  } else {
+    rbd::eval_f<NJ>(m, x, u, f1);
+  }
   const double* f0 = p.f_val + bt * n;
   const double* fcol = at_x ? p.fx + bt * n * n + (int64_t)idx * n : p.fu + bt * n * mm + (int64_t)idx * n;
   double* tensor = at_x ? p.fxx + bt * n * n * n : p.fuu + bt * n * mm * mm;
@@ -146,27 +173,40 @@ __global__ void lin_diag_kernel(LinParams p) {
   }
 }
 
-// off-diagonal entries, :226-296: one lane per unordered pair i < j of the n+m directions
-template <int NJ>
+// off-diagonal entries, :226-296: one lane per unordered pair i < j of the n+m directions.
+// PAIRS = 0: every pair, full ABA (no q-cache).  PAIRS = 1: the pairs of two q directions (both perturb the
+// configuration: full ABA).  PAIRS = 2: every other pair: at most one q direction, the q-dependent part comes from the cache.
+template <int NJ, int PAIRS>
 __global__ void lin_offdiag_kernel(LinParams p) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t T = p.d.T;
   const int n = (int)p.d.n, mm = (int)p.d.m;
   const int W = n + mm;
-  const int64_t P = (int64_t)W * (W - 1) / 2;
+  const DevModel& m = *p.model;
+  const int nv = m.nv;
+  const int VU = W - nv;                                   // directions that leave q alone
+  const int64_t P = PAIRS == 0 ? (int64_t)W * (W - 1) / 2
+                  : PAIRS == 1 ? (int64_t)nv * (nv - 1) / 2
+                               : (int64_t)nv * VU + (int64_t)VU * (VU - 1) / 2;
   if (gid >= p.d.batch * T * P) return;
   const int64_t pid = gid % P;
   const int64_t bt = gid / P;
   const int b = (int)(bt / T);
   const int64_t t = bt % T;
-  // pid -> (i, j), i < j, enumerated row by row
-  int i = (int)floor(((2.0 * W - 1.0) - sqrt((2.0 * W - 1.0) * (2.0 * W - 1.0) - 8.0 * (double)pid)) * 0.5);
-  if (i < 0) i = 0;
-  while ((int64_t)i * (2 * W - i - 1) / 2 > pid) --i;
-  while ((int64_t)(i + 1) * (2 * W - i - 2) / 2 <= pid) ++i;
-  const int j = (int)(pid - (int64_t)i * (2 * W - i - 1) / 2) + i + 1;
+  auto tri = [](int64_t q, int Wd, int& ii, int& jj) {      // q -> (ii, jj), ii < jj < Wd, enumerated row by row
+    int a = (int)floor(((2.0 * Wd - 1.0) - sqrt((2.0 * Wd - 1.0) * (2.0 * Wd - 1.0) - 8.0 * (double)q)) * 0.5);
+    if (a < 0) a = 0;
+    while ((int64_t)a * (2 * Wd - a - 1) / 2 > q) --a;
+    while ((int64_t)(a + 1) * (2 * Wd - a - 2) / 2 <= q) ++a;
+    ii = a;
+    jj = (int)(q - (int64_t)a * (2 * Wd - a - 1) / 2) + a + 1;
+  };
+  int i, j;
+  if (PAIRS == 0) tri(pid, W, i, j);
+  else if (PAIRS == 1) tri(pid, nv, i, j);
+  else if (pid < (int64_t)nv * VU) { i = (int)(pid / VU); j = nv + (int)(pid % VU); }
+  else { tri(pid - (int64_t)nv * VU, VU, i, j); i += nv; j += nv; }
 
-  const DevModel& m = *p.model;
   double x[2 * NJ], u[NJ], f1[2 * NJ];
   load_xu<NJ>(p, b, t, x, u);
   const double eps = sqrt(sqrt(DBL_EPSILON));
@@ -175,7 +215,12 @@ __global__ void lin_offdiag_kernel(LinParams p) {
   const int idx_1 = at_x_1 ? i : i - n, idx_2 = at_x_2 ? j : j - n;
   if (at_x_1) x[idx_1] = x[idx_1] + eps; else u[idx_1] = u[idx_1] + eps;
   if (at_x_2) x[idx_2] = x[idx_2] + eps; else u[idx_2] = u[idx_2] + eps;
-  rbd::eval_f<NJ>(m, x, u, f1);
+  if (PAIRS == 2) {
+    const int cfg = i < nv ? 1 + i : 0;
+    rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
+  } else {
+    rbd::eval_f<NJ>(m, x, u, f1);
+  }
   const double* f0 = p.f_val + bt * n;
   double* fxx = p.fxx + bt * n * n * n;
   double* fux = p.fux + bt * n * mm * n;
@@ -454,6 +499,7 @@ LinParams make_params(ddp_hip_ctx* ctx) {
   p.eq_val = S(DDP_HIP_SEQ_EQ_VAL); p.eq_x = S(DDP_HIP_SEQ_EQ_X); p.eq_u = S(DDP_HIP_SEQ_EQ_U);
   p.eq_xx = S(DDP_HIP_SEQ_EQ_XX); p.eq_ux = S(DDP_HIP_SEQ_EQ_UX); p.eq_uu = S(DDP_HIP_SEQ_EQ_UU);
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
+  p.qcache = reinterpret_cast<double*>(ctx->lin_ws);
   return p;
 }
 
@@ -478,8 +524,17 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
   if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors) {
     prof_begin(ctx, DDP_HIP_K_LIN_SECOND);
     if (fd_mode == 2) {
-      hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
-      hipLaunchKernelGGL((lin_offdiag_kernel<NJ>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p);
+      if (p.qcache) {
+        const int nv = (int)d.nv, VU = W - nv;
+        const int64_t Pqq = (int64_t)nv * (nv - 1) / 2, Prest = (int64_t)nv * VU + (int64_t)VU * (VU - 1) / 2;
+        hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * Pqq)), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Prest)), dim3(LBS), 0, ctx->stream, p);
+      } else {
+        hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 0>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p);
+      }
     } else if (fd_mode == 1) {
       if constexpr (small) {
         if (ctx->model_h.first_order_fd) return DDP_HIP_E_UNSUPPORTED;  // FD of FD jacobians is numerically void
@@ -516,8 +571,20 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
 
 }  // namespace
 
-int lin_setup(ddp_hip_ctx*) { return DDP_HIP_OK; }
-void lin_teardown(ddp_hip_ctx*) {}
+int lin_setup(ddp_hip_ctx* ctx) {
+  // q-part cache of the mode-2 stencil (tree models with resident tensors only)
+  const bool want = ctx->model_h.kind == DDP_HIP_MODEL_TREE && ctx->model_h.fd_mode == 2 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS) &&
+                    getenv("DDP_HIP_NO_QCACHE") == nullptr;
+  if (want) {
+    const Dims& d = ctx->d;
+    ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * (d.nv + 1) * d.nv * rbd::QC_STRIDE);
+    HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));
+  }
+  return DDP_HIP_OK;
+}
+void lin_teardown(ddp_hip_ctx* ctx) {
+  if (ctx->lin_ws) (void)hipFree(ctx->lin_ws);
+}
 
 extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   if (!ctx) return DDP_HIP_E_ARG;

@@ -289,3 +289,259 @@ __device__ void frame_position(const DevModel& m, const double* q, double* p3, d
 }
 
 }  // namespace rbd
+
+// ---- articulated-body algorithm split by what each part depends on --------------------------------------------
+// The finite-difference stencils evaluate the dynamics at thousands of points that share their configuration q:
+// everything the ABA derives from q alone (joint placements, articulated inertias, U = IA S, 1/D, the projected
+// inertia Ia) is computed once per distinct q (aba_qpart) and read back by every evaluation that only varies v or
+// tau (aba_vu_cached).  The cached part is the very same sequence of operations as in aba_tree, so the split changes
+// nothing but the amount of repeated work.
+namespace rbd {
+
+constexpr int QC_STRIDE = 40;   // per joint: E[9] r[3] U[6] Dinv Ia[21]
+
+template <int NJ>
+__device__ void aba_qpart(const DevModel& m, const double* q, double* __restrict__ qc) {
+  const int N = m.nv;
+  double E[NJ][9], R[NJ][3], IA[NJ][21];
+  for (int i = 0; i < N; ++i) {
+    joint_placement(m, i, q[i], E[i], R[i]);
+    for (int k = 0; k < 21; ++k) IA[i][k] = m.I6[i][k];
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    const double* a = m.axis[i];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    double U[6], d = 0;
+    for (int r = 0; r < 6; ++r) U[r] = IA[i][sidx(r, o)] * a[0] + IA[i][sidx(r, o + 1)] * a[1] + IA[i][sidx(r, o + 2)] * a[2];
+    for (int k = 0; k < 3; ++k) d += a[k] * U[o + k];
+    const double dinv = 1.0 / d;
+    double Ia[21];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[i][sidx(r, c)] - U[r] * U[c] * dinv;
+    const int par = m.parent[i];
+    if (par >= 0) add_xtix(E[i], R[i], Ia, IA[par]);
+    double* o_ = qc + i * QC_STRIDE;
+    for (int k = 0; k < 9; ++k) o_[k] = E[i][k];
+    for (int k = 0; k < 3; ++k) o_[9 + k] = R[i][k];
+    for (int k = 0; k < 6; ++k) o_[12 + k] = U[k];
+    o_[18] = dinv;
+    for (int k = 0; k < 21; ++k) o_[19 + k] = Ia[k];
+  }
+}
+
+template <int NJ>
+__device__ void aba_vu_cached(const DevModel& m, const double* __restrict__ qc, const double* v, const double* tau, double* qdd) {
+  const int N = m.nv;
+  double cb[NJ][6], pA[NJ][6], uu[NJ];
+  {
+    double vel[NJ][6];
+    for (int i = 0; i < N; ++i) {
+      const double* E = qc + i * QC_STRIDE;
+      const double* r = E + 9;
+      const double* a = m.axis[i];
+      double vJ[6] = {0, 0, 0, 0, 0, 0};
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+      const int par = m.parent[i];
+      if (par >= 0) xform_motion(E, r, vel[par], vel[i]);
+      else { for (int k = 0; k < 6; ++k) vel[i][k] = 0.0; }
+      for (int k = 0; k < 6; ++k) vel[i][k] += vJ[k];
+      crm(vel[i], vJ, cb[i]);
+      double Iv[6];
+      sym6_mv(m.I6[i], vel[i], Iv);
+      crf(vel[i], Iv, pA[i]);
+    }
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    const double* E = qc + i * QC_STRIDE;
+    const double* r = E + 9;
+    const double* U = E + 12;
+    const double dinv = E[18];
+    const double* Ia = E + 19;
+    const double* a = m.axis[i];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    double sp = 0;
+    for (int k = 0; k < 3; ++k) sp += a[k] * pA[i][o + k];
+    uu[i] = tau[i] - sp;
+    const int par = m.parent[i];
+    if (par >= 0) {
+      double pa[6], Iac[6], fp[6];
+      sym6_mv(Ia, cb[i], Iac);
+      for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[k] * (uu[i] * dinv);
+      xform_force_T(E, r, pa, fp);
+      for (int k = 0; k < 6; ++k) pA[par][k] += fp[k];
+    }
+  }
+  {
+    double acc[NJ][6];
+    for (int i = 0; i < N; ++i) {
+      const double* E = qc + i * QC_STRIDE;
+      const double* r = E + 9;
+      const double* U = E + 12;
+      const double dinv = E[18];
+      double ap[6];
+      const int par = m.parent[i];
+      if (par >= 0) xform_motion(E, r, acc[par], ap);
+      else {
+        const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+        xform_motion(E, r, a0, ap);
+      }
+      double s = 0;
+      for (int k = 0; k < 6; ++k) { ap[k] += cb[i][k]; s += U[k] * ap[k]; }
+      const double qd = (uu[i] - s) * dinv;
+      qdd[i] = qd;
+      const double* a = m.axis[i];
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
+      acc[i][o] += a[0] * qd; acc[i][o + 1] += a[1] * qd; acc[i][o + 2] += a[2] * qd;
+    }
+  }
+}
+
+// eval_to (problem.hpp:441-461) with the q-dependent part of the ABA taken from `qc` (computed at x's configuration)
+template <int NJ>
+__device__ void eval_f_cached(const DevModel& m, const double* __restrict__ qc, const double* x, const double* u, double* x_out) {
+  const int nv = m.nv;
+  double acc[NJ];
+  aba_vu_cached<NJ>(m, qc, x + nv, u, acc);
+  for (int i = 0; i < nv; ++i) {
+    const double vo = m.dt * x[nv + i];
+    x_out[i] = x[i] + vo;
+    x_out[nv + i] = x[nv + i] + acc[i] * m.dt;
+  }
+}
+
+}  // namespace rbd
+
+// ---- latency-oriented variant: per-evaluation state in LDS instead of scratch ------------------------------------
+// The closed-loop rollouts of the forward sweep are a few hundred sequential chains: too few lanes to hide the
+// latency of scratch (private HBM-backed) arrays.  Here the per-joint state of one evaluation lives in LDS,
+// interleaved over the TPB lanes of the workgroup ([slot][lane], conflict free); same arithmetic as aba_tree.
+namespace rbd {
+
+constexpr int ABA_LDS_SLOTS = 59;   // per joint: E 9 | r 3 | cb 6 | pA 6 | IA 21 | U 6 | Dinv 1 | uu 1 | vel/acc 6
+
+template <int NJ, int TPB>
+__device__ void aba_tree_lds(const DevModel& m, const double* q, const double* v, const double* tau, double* qdd,
+                             double* st, int lane) {
+  const int N = m.nv;
+  auto S = [&](int joint, int slot) -> double& { return st[(joint * ABA_LDS_SLOTS + slot) * TPB + lane]; };
+  constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oI = 24, oU = 45, oD = 51, oT = 52, oV = 53;
+  for (int i = 0; i < N; ++i) {
+    double E[9], R[3], vel[6], vp[6], cb[6], pA[6], Iv[6], I6[21];
+    joint_placement(m, i, q[i], E, R);
+    const double* a = m.axis[i];
+    double vJ[6] = {0, 0, 0, 0, 0, 0};
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+    const int par = m.parent[i];
+    if (par >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vp[k] = S(par, oV + k);
+      xform_motion(E, R, vp, vel);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+    crm(vel, vJ, cb);
+#pragma unroll
+    for (int k = 0; k < 21; ++k) I6[k] = m.I6[i][k];
+    sym6_mv(I6, vel, Iv);
+    crf(vel, Iv, pA);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S(i, oE + k) = E[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S(i, oR + k) = R[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { S(i, oV + k) = vel[k]; S(i, oC + k) = cb[k]; S(i, oP + k) = pA[k]; }
+#pragma unroll
+    for (int k = 0; k < 21; ++k) S(i, oI + k) = I6[k];
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    const double* a = m.axis[i];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    double IA[21], U[6], pAi[6], cb[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA[k] = S(i, oI + k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { pAi[k] = S(i, oP + k); cb[k] = S(i, oC + k); }
+    double d = 0, sp = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) U[r] = IA[sidx(r, o)] * a[0] + IA[sidx(r, o + 1)] * a[1] + IA[sidx(r, o + 2)] * a[2];
+    for (int k = 0; k < 3; ++k) { d += a[k] * U[o + k]; sp += a[k] * pAi[o + k]; }
+    const double dinv = 1.0 / d;
+    const double ui = tau[i] - sp;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S(i, oU + k) = U[k];
+    S(i, oD) = dinv;
+    S(i, oT) = ui;
+    const int par = m.parent[i];
+    if (par >= 0) {
+      double E[9], R[3], Ia[21], pa[6], Iac[6], fp[6], IAp[21];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[sidx(r, c)] - U[r] * U[c] * dinv;
+      sym6_mv(Ia, cb, Iac);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) IAp[k] = S(par, oI + k);
+      add_xtix(E, R, Ia, IAp);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) S(par, oI + k) = IAp[k];
+      xform_force_T(E, R, pa, fp);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S(par, oP + k) += fp[k];
+    }
+  }
+  for (int i = 0; i < N; ++i) {
+    double E[9], R[3], ap[6], accp[6], U[6], cb[6];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { U[k] = S(i, oU + k); cb[k] = S(i, oC + k); }
+    const int par = m.parent[i];
+    if (par >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) accp[k] = S(par, oV + k);
+      xform_motion(E, R, accp, ap);
+    } else {
+      const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+      xform_motion(E, R, a0, ap);
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; s += U[k] * ap[k]; }
+    const double qd = (S(i, oT) - s) * S(i, oD);
+    qdd[i] = qd;
+    const double* a = m.axis[i];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    ap[o] += a[0] * qd; ap[o + 1] += a[1] * qd; ap[o + 2] += a[2] * qd;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S(i, oV + k) = ap[k];
+  }
+}
+
+template <int NJ, int TPB>
+__device__ void eval_f_lds(const DevModel& m, const double* x, const double* u, double* x_out, double* st, int lane) {
+  const int nv = m.nv;
+  if (m.kind == DDP_HIP_MODEL_PENDULUM) { eval_f<NJ>(m, x, u, x_out); return; }
+  double acc[NJ];
+  aba_tree_lds<NJ, TPB>(m, x, x + nv, u, acc, st, lane);
+  for (int i = 0; i < nv; ++i) {
+    const double vo = m.dt * x[nv + i];
+    x_out[i] = x[i] + vo;
+    x_out[nv + i] = x[nv + i] + acc[i] * m.dt;
+  }
+}
+
+}  // namespace rbd
