@@ -29,6 +29,7 @@ struct LinParams {
   double *f_val, *fx, *fu, *fxx, *fux, *fuu;
   double *eq_val, *eq_x, *eq_u, *eq_xx, *eq_ux, *eq_uu;
   int32_t has_tensors;
+  double* vcache;   // [batch*T][2nv+1][nv*VC_STRIDE]: (q, v)-dependent part at (q,v), (q, v+eps e_i), (q+eps e_i, v)
   double* qcache;   // [batch*T][nv+1][nv*QC_STRIDE]: q-dependent part of the ABA at the base q and at q + eps e_i (mode 2)
 };
 
@@ -135,6 +136,28 @@ __global__ void lin_qcache_kernel(LinParams p) {
   rbd::aba_qpart<NJ>(m, x, p.qcache + (bt * C + cfg) * (int64_t)nv * rbd::QC_STRIDE);
 }
 
+// (q, v)-dependent part for the 2 nv + 1 (q, v) pairs shared by several stencil points:
+// vcfg 0 = (q, v), 1+i = (q, v + eps e_i), nv+1+i = (q + eps e_i, v)
+template <int NJ>
+__global__ void lin_vcache_kernel(LinParams p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t T = p.d.T;
+  const DevModel& m = *p.model;
+  const int nv = m.nv, C = 2 * nv + 1;
+  if (gid >= p.d.batch * T * C) return;
+  const int vcfg = (int)(gid % C);
+  const int64_t bt = gid / C;
+  const int b = (int)(bt / T);
+  const int64_t t = bt % T;
+  double x[2 * NJ], u[NJ];
+  load_xu<NJ>(p, b, t, x, u);
+  const double eps = sqrt(sqrt(DBL_EPSILON));
+  if (vcfg >= 1 && vcfg <= nv) x[nv + vcfg - 1] = x[nv + vcfg - 1] + eps;
+  const int cfg = vcfg > nv ? vcfg - nv : 0;
+  rbd::aba_vpart_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x + nv,
+                            p.vcache + (bt * C + vcfg) * (int64_t)nv * rbd::VC_STRIDE);
+}
+
 // diagonal entries, :192-222
 template <int NJ>
 __global__ void lin_diag_kernel(LinParams p) {
@@ -157,7 +180,9 @@ __global__ void lin_diag_kernel(LinParams p) {
   if (at_x) x[idx] = x[idx] + eps; else u[idx] = u[idx] + eps;
   if (p.qcache) {
     const int nv = m.nv, cfg = (at_x && idx < nv) ? 1 + idx : 0;
-    rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
+    const double* qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
+    if (!at_x) rbd::eval_f_ucached<NJ>(m, qc, p.vcache + (bt * (2 * nv + 1)) * (int64_t)nv * rbd::VC_STRIDE, x, u, f1);
+    else rbd::eval_f_cached<NJ>(m, qc, x, u, f1);
   } else {
     rbd::eval_f<NJ>(m, x, u, f1);
   }
@@ -174,23 +199,25 @@ __global__ void lin_diag_kernel(LinParams p) {
 }
 
 // off-diagonal entries, :226-296: one lane per unordered pair i < j of the n+m directions.
-// PAIRS = 0: every pair, full ABA (no q-cache).  PAIRS = 1: the pairs of two q directions (both perturb the
-// configuration: full ABA).  PAIRS = 2: every other pair: at most one q direction, the q-dependent part comes from the cache.
+// PAIRS = 0: every pair, full ABA (no caches).  PAIRS = 1: two q directions (both perturb the configuration: full
+// ABA).  PAIRS = 2: (q or v, v): the q-dependent part comes from the q-cache.  PAIRS = 3: (q, v or u; u): only tau
+// differs from a cached (q, v) pair, the evaluation is the force / acceleration passes alone.
 template <int NJ, int PAIRS>
-__global__ void lin_offdiag_kernel(LinParams p) {
+__global__ __launch_bounds__(LBS) void lin_offdiag_kernel(LinParams p) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t T = p.d.T;
   const int n = (int)p.d.n, mm = (int)p.d.m;
   const int W = n + mm;
   const DevModel& m = *p.model;
   const int nv = m.nv;
-  const int VU = W - nv;                                   // directions that leave q alone
+  const int64_t TRI = (int64_t)nv * (nv - 1) / 2;
   const int64_t P = PAIRS == 0 ? (int64_t)W * (W - 1) / 2
-                  : PAIRS == 1 ? (int64_t)nv * (nv - 1) / 2
-                               : (int64_t)nv * VU + (int64_t)VU * (VU - 1) / 2;
-  if (gid >= p.d.batch * T * P) return;
-  const int64_t pid = gid % P;
-  const int64_t bt = gid / P;
+                  : PAIRS == 1 ? TRI
+                  : PAIRS == 2 ? (int64_t)nv * nv + TRI
+                               : 2 * (int64_t)nv * nv + TRI;
+  const bool valid = gid < p.d.batch * T * P;
+  const int64_t pid = valid ? gid % P : 0;
+  const int64_t bt = valid ? gid / P : 0;
   const int b = (int)(bt / T);
   const int64_t t = bt % T;
   auto tri = [](int64_t q, int Wd, int& ii, int& jj) {      // q -> (ii, jj), ii < jj < Wd, enumerated row by row
@@ -204,45 +231,85 @@ __global__ void lin_offdiag_kernel(LinParams p) {
   int i, j;
   if (PAIRS == 0) tri(pid, W, i, j);
   else if (PAIRS == 1) tri(pid, nv, i, j);
-  else if (pid < (int64_t)nv * VU) { i = (int)(pid / VU); j = nv + (int)(pid % VU); }
-  else { tri(pid - (int64_t)nv * VU, VU, i, j); i += nv; j += nv; }
+  else if (PAIRS == 2) {
+    if (pid < (int64_t)nv * nv) { i = (int)(pid / nv); j = nv + (int)(pid % nv); }                 // (q_i, v_j)
+    else { tri(pid - (int64_t)nv * nv, nv, i, j); i += nv; j += nv; }                              // (v_i, v_j)
+  } else {
+    if (pid < 2 * (int64_t)nv * nv) { i = (int)(pid / nv); j = 2 * nv + (int)(pid % nv); }         // (q_i or v_i, u_j)
+    else { tri(pid - 2 * (int64_t)nv * nv, nv, i, j); i += 2 * nv; j += 2 * nv; }                  // (u_i, u_j)
+  }
 
-  double x[2 * NJ], u[NJ], f1[2 * NJ];
-  load_xu<NJ>(p, b, t, x, u);
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
-  const bool at_x_1 = i < n, at_x_2 = j < n;
-  const int idx_1 = at_x_1 ? i : i - n, idx_2 = at_x_2 ? j : j - n;
-  if (at_x_1) x[idx_1] = x[idx_1] + eps; else u[idx_1] = u[idx_1] + eps;
-  if (at_x_2) x[idx_2] = x[idx_2] + eps; else u[idx_2] = u[idx_2] + eps;
-  if (PAIRS == 2) {
-    const int cfg = i < nv ? 1 + i : 0;
-    rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
-  } else {
-    rbd::eval_f<NJ>(m, x, u, f1);
+  double f1[2 * NJ];
+  if (valid) {
+    double x[2 * NJ], u[NJ];
+    load_xu<NJ>(p, b, t, x, u);
+    if (i < n) x[i] = x[i] + eps; else u[i - n] = u[i - n] + eps;
+    if (j < n) x[j] = x[j] + eps; else u[j - n] = u[j - n] + eps;
+    if (PAIRS == 2) {
+      const int cfg = i < nv ? 1 + i : 0;
+      rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
+    } else if (PAIRS == 3) {
+      const int cfg = i < nv ? 1 + i : 0;
+      const int vcfg = i < nv ? nv + 1 + i : (i < 2 * nv ? 1 + (i - nv) : 0);
+      rbd::eval_f_ucached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE,
+                              p.vcache + (bt * (2 * nv + 1) + vcfg) * (int64_t)nv * rbd::VC_STRIDE, x, u, f1);
+    } else {
+      rbd::eval_f<NJ>(m, x, u, f1);
+    }
   }
-  const double* f0 = p.f_val + bt * n;
-  double* fxx = p.fxx + bt * n * n * n;
-  double* fux = p.fux + bt * n * mm * n;
-  double* fuu = p.fuu + bt * n * mm * mm;
-  const double* fcol_1 = at_x_1 ? p.fx + bt * n * n + (int64_t)idx_1 * n : p.fu + bt * n * mm + (int64_t)idx_1 * n;
-  const double* fcol_2 = at_x_2 ? p.fx + bt * n * n + (int64_t)idx_2 * n : p.fu + bt * n * mm + (int64_t)idx_2 * n;
-  const double* tensor_1 = at_x_1 ? fxx : fuu;
-  const double* tensor_2 = at_x_2 ? fxx : fuu;
-  const int L1 = at_x_1 ? n : mm, L2 = at_x_2 ? n : mm;
-  double* tensor;
-  int L;
-  if (at_x_1) { if (at_x_2) { tensor = fxx; L = n; } else { tensor = fux; L = mm; } }
-  else { tensor = fuu; L = mm; }
-  for (int k = 0; k < n; ++k) {
-    double df = f1[k] - f0[k];
-    df -= eps * fcol_1[k];
-    df -= eps * fcol_2[k];
-    df *= 2;
-    const double val = 0.5 * (df / eps2 - tensor_1[k + (int64_t)idx_1 * n + (int64_t)idx_1 * n * L1] -
-                              tensor_2[k + (int64_t)idx_2 * n + (int64_t)idx_2 * n * L2]);
-    tensor[k + (int64_t)idx_2 * n + (int64_t)idx_1 * n * L] = val;
-    if (at_x_1 == at_x_2) tensor[k + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L] = val;
+
+  // Output stage.  Each stencil point owns one 76-double column of a tensor (and reads five more columns);
+  // done lane-per-point that is 64 scattered 8-byte accesses per instruction.  Instead the wave transposes the
+  // f(x+dx) values through LDS, 16 rows at a time, and walks the points four at a time with 16 lanes on each
+  // column: every access is four 128-byte runs.
+  constexpr int CH = 16, EPI = LBS / CH;               // rows per chunk, points per instruction
+  __shared__ double s_f[CH][LBS];
+  __shared__ int s_i[LBS], s_j[LBS];
+  __shared__ int64_t s_bt[LBS];
+  const int lane = threadIdx.x;
+  s_i[lane] = valid ? i : -1;
+  s_j[lane] = j;
+  s_bt[lane] = bt;
+  const int kk = lane % CH, esub = lane / CH;
+  for (int c0 = 0; c0 < n; c0 += CH) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+      if (c0 + q < n) s_f[q][lane] = f1[c0 + q];
+    __syncthreads();
+    const int k = c0 + kk;
+    for (int r = 0; r < LBS / EPI; ++r) {
+      const int e = r * EPI + esub;
+      const int ie = s_i[e];
+      if (ie < 0 || k >= n) continue;
+      const int je = s_j[e];
+      const int64_t bte = s_bt[e];
+      const bool at_x_1 = ie < n, at_x_2 = je < n;
+      const int idx_1 = at_x_1 ? ie : ie - n, idx_2 = at_x_2 ? je : je - n;
+      const double* f0 = p.f_val + bte * n;
+      double* fxx = p.fxx + bte * n * n * n;
+      double* fux = p.fux + bte * n * mm * n;
+      double* fuu = p.fuu + bte * n * mm * mm;
+      const double* fcol_1 = at_x_1 ? p.fx + bte * n * n + (int64_t)idx_1 * n : p.fu + bte * n * mm + (int64_t)idx_1 * n;
+      const double* fcol_2 = at_x_2 ? p.fx + bte * n * n + (int64_t)idx_2 * n : p.fu + bte * n * mm + (int64_t)idx_2 * n;
+      const double* tensor_1 = at_x_1 ? fxx : fuu;
+      const double* tensor_2 = at_x_2 ? fxx : fuu;
+      const int L1 = at_x_1 ? n : mm, L2 = at_x_2 ? n : mm;
+      double* tensor;
+      int L;
+      if (at_x_1) { if (at_x_2) { tensor = fxx; L = n; } else { tensor = fux; L = mm; } }
+      else { tensor = fuu; L = mm; }
+      double df = s_f[kk][e] - f0[k];                     // difference_out
+      df -= eps * fcol_1[k];
+      df -= eps * fcol_2[k];
+      df *= 2;
+      const double val = 0.5 * (df / eps2 - tensor_1[k + (int64_t)idx_1 * n + (int64_t)idx_1 * n * L1] -
+                                tensor_2[k + (int64_t)idx_2 * n + (int64_t)idx_2 * n * L2]);
+      tensor[k + (int64_t)idx_2 * n + (int64_t)idx_1 * n * L] = val;
+      if (at_x_1 == at_x_2) tensor[k + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L] = val;
+    }
+    __syncthreads();
   }
 }
 
@@ -500,6 +567,7 @@ LinParams make_params(ddp_hip_ctx* ctx) {
   p.eq_xx = S(DDP_HIP_SEQ_EQ_XX); p.eq_ux = S(DDP_HIP_SEQ_EQ_UX); p.eq_uu = S(DDP_HIP_SEQ_EQ_UU);
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
   p.qcache = reinterpret_cast<double*>(ctx->lin_ws);
+  p.vcache = p.qcache ? p.qcache + ctx->d.batch * ctx->d.T * (ctx->d.nv + 1) * ctx->d.nv * rbd::QC_STRIDE : nullptr;
   return p;
 }
 
@@ -525,12 +593,14 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     prof_begin(ctx, DDP_HIP_K_LIN_SECOND);
     if (fd_mode == 2) {
       if (p.qcache) {
-        const int nv = (int)d.nv, VU = W - nv;
-        const int64_t Pqq = (int64_t)nv * (nv - 1) / 2, Prest = (int64_t)nv * VU + (int64_t)VU * (VU - 1) / 2;
+        const int nv = (int)d.nv;
+        const int64_t TRI = (int64_t)nv * (nv - 1) / 2, Pv = (int64_t)nv * nv + TRI, Pu = 2 * (int64_t)nv * nv + TRI;
         hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
-        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * Pqq)), dim3(LBS), 0, ctx->stream, p);
-        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Prest)), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
+        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 3>), dim3(blocks_for(BT * Pu)), dim3(LBS), 0, ctx->stream, p);
       } else {
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 0>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p);
@@ -577,7 +647,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
                     getenv("DDP_HIP_NO_QCACHE") == nullptr;
   if (want) {
     const Dims& d = ctx->d;
-    ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * (d.nv + 1) * d.nv * rbd::QC_STRIDE);
+    ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * ((d.nv + 1) * d.nv * rbd::QC_STRIDE + (2 * d.nv + 1) * d.nv * rbd::VC_STRIDE));
     HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));
   }
   return DDP_HIP_OK;

@@ -545,3 +545,102 @@ __device__ void eval_f_lds(const DevModel& m, const double* x, const double* u, 
 }
 
 }  // namespace rbd
+
+// ---- second level of the split: what depends on (q, v) but not on tau ---------------------------------------------
+namespace rbd {
+
+constexpr int VC_STRIDE = 18;   // per joint: cb[6] | pA0[6] (bias force before the children's contributions) | Ia cb [6]
+
+// pass 1 of aba_vu_cached + the product Ia cb of its pass 2, stored for every evaluation that shares (q, v)
+template <int NJ>
+__device__ void aba_vpart_cached(const DevModel& m, const double* __restrict__ qc, const double* v, double* __restrict__ vc) {
+  const int N = m.nv;
+  double vel[NJ][6];
+  for (int i = 0; i < N; ++i) {
+    const double* E = qc + i * QC_STRIDE;
+    const double* r = E + 9;
+    const double* Ia = E + 19;
+    const double* a = m.axis[i];
+    double vJ[6] = {0, 0, 0, 0, 0, 0};
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+    const int par = m.parent[i];
+    if (par >= 0) xform_motion(E, r, vel[par], vel[i]);
+    else { for (int k = 0; k < 6; ++k) vel[i][k] = 0.0; }
+    for (int k = 0; k < 6; ++k) vel[i][k] += vJ[k];
+    double cb[6], pA[6], Iv[6], Iac[6];
+    crm(vel[i], vJ, cb);
+    sym6_mv(m.I6[i], vel[i], Iv);
+    crf(vel[i], Iv, pA);
+    sym6_mv(Ia, cb, Iac);
+    double* o_ = vc + i * VC_STRIDE;
+    for (int k = 0; k < 6; ++k) { o_[k] = cb[k]; o_[6 + k] = pA[k]; o_[12 + k] = Iac[k]; }
+  }
+}
+
+// passes 2 and 3 of aba_vu_cached for a new tau
+template <int NJ>
+__device__ void aba_u_cached(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc, const double* tau,
+                             double* qdd) {
+  const int N = m.nv;
+  double pA[NJ][6], uu[NJ];
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k < 6; ++k) pA[i][k] = vc[i * VC_STRIDE + 6 + k];
+  for (int i = N - 1; i >= 0; --i) {
+    const double* E = qc + i * QC_STRIDE;
+    const double* r = E + 9;
+    const double* U = E + 12;
+    const double dinv = E[18];
+    const double* Iac = vc + i * VC_STRIDE + 12;
+    const double* a = m.axis[i];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    double sp = 0;
+    for (int k = 0; k < 3; ++k) sp += a[k] * pA[i][o + k];
+    uu[i] = tau[i] - sp;
+    const int par = m.parent[i];
+    if (par >= 0) {
+      double pa[6], fp[6];
+      for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[k] * (uu[i] * dinv);
+      xform_force_T(E, r, pa, fp);
+      for (int k = 0; k < 6; ++k) pA[par][k] += fp[k];
+    }
+  }
+  double (*acc)[6] = pA;   // pass 3 reuses the storage of the (now dead) bias forces
+  for (int i = 0; i < N; ++i) {
+    const double* E = qc + i * QC_STRIDE;
+    const double* r = E + 9;
+    const double* U = E + 12;
+    const double dinv = E[18];
+    const double* cb = vc + i * VC_STRIDE;
+    double ap[6];
+    const int par = m.parent[i];
+    if (par >= 0) xform_motion(E, r, acc[par], ap);
+    else {
+      const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+      xform_motion(E, r, a0, ap);
+    }
+    double s = 0;
+    for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; s += U[k] * ap[k]; }
+    const double qd = (uu[i] - s) * dinv;
+    qdd[i] = qd;
+    const double* a = m.axis[i];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
+    acc[i][o] += a[0] * qd; acc[i][o + 1] += a[1] * qd; acc[i][o + 2] += a[2] * qd;
+  }
+}
+
+template <int NJ>
+__device__ void eval_f_ucached(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc, const double* x,
+                               const double* u, double* x_out) {
+  const int nv = m.nv;
+  double acc[NJ];
+  aba_u_cached<NJ>(m, qc, vc, u, acc);
+  for (int i = 0; i < nv; ++i) {
+    const double vo = m.dt * x[nv + i];
+    x_out[i] = x[i] + vo;
+    x_out[nv + i] = x[nv + i] + acc[i] * m.dt;
+  }
+}
+
+}  // namespace rbd
