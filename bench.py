@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seeds-per-gpu", type=int, default=16)
+    ap.add_argument("--seeds-per-gpu", type=int, default=64)
     ap.add_argument("--horizon", type=int, default=200)
     ap.add_argument("--mode", choices=["full", "gn"], default="full",
                     help="full = with second-order tensors (the reference's algorithm); gn = tensor-free variant")

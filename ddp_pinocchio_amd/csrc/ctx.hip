@@ -52,6 +52,53 @@ static void pack_body_inertia(const ddp_hip_model* m, int i, double* out21) {
     for (int cc2 = 0; cc2 <= r; ++cc2) out21[p++] = I6[r][cc2];
 }
 
+// Slot tables for the small-state tree traversals (rbd.h: aba_u_cached).  Leaf->root (descending index): a joint's
+// accumulator is allocated when its largest-index child contributes and freed once the joint itself is processed.
+// Root->leaf (ascending index): a joint's value is kept from when it is processed until its largest-index child
+// has read it.  For a humanoid tree a handful of slots suffice.
+static bool build_slot_tables(DevModel& dm) {
+  const int N = dm.nv;
+  int largest_child[DDP_MAXJ];
+  for (int i = 0; i < N; ++i) { dm.has_child[i] = 0; largest_child[i] = -1; dm.slot_up[i] = -1; dm.slot_down[i] = -1; }
+  for (int i = 0; i < N; ++i)
+    if (dm.parent[i] >= 0) { dm.has_child[dm.parent[i]] = 1; if (i > largest_child[dm.parent[i]]) largest_child[dm.parent[i]] = i; }
+  for (int i = 0; i < N; ++i) {
+    const int par = dm.parent[i];
+    dm.first_contrib[i] = dm.last_child[i] = (par >= 0 && largest_child[par] == i) ? 1 : 0;
+  }
+  const int MAXS = 16;
+  bool used[MAXS];
+  int n_slots = 0;
+  for (int k = 0; k < MAXS; ++k) used[k] = false;
+  for (int i = N - 1; i >= 0; --i) {            // leaf -> root
+    const int par = dm.parent[i];
+    if (par >= 0 && dm.first_contrib[i]) {
+      int k = 0;
+      while (k < MAXS && used[k]) ++k;
+      if (k == MAXS) return false;
+      used[k] = true;
+      dm.slot_up[par] = k;
+      if (k + 1 > n_slots) n_slots = k + 1;
+    }
+    if (dm.slot_up[i] >= 0) used[dm.slot_up[i]] = false;   // the joint is processed: its accumulator is consumed
+  }
+  for (int k = 0; k < MAXS; ++k) used[k] = false;
+  for (int i = 0; i < N; ++i) {                 // root -> leaf
+    if (dm.has_child[i]) {
+      int k = 0;
+      while (k < MAXS && used[k]) ++k;
+      if (k == MAXS) return false;
+      used[k] = true;
+      dm.slot_down[i] = k;
+      if (k + 1 > n_slots) n_slots = k + 1;
+    }
+    const int par = dm.parent[i];
+    if (par >= 0 && dm.last_child[i]) used[dm.slot_down[par]] = false;
+  }
+  dm.n_slots = n_slots;
+  return n_slots <= 8;   // rbd::MAX_SLOTS
+}
+
 static int64_t seq_size_of(const Dims& d, int s) {
   const int64_t T = d.T, n = d.n, m = d.m, nx = d.nx, E = d.Etot;
   switch (s) {
@@ -194,6 +241,7 @@ extern "C" int ddp_hip_create(const ddp_hip_problem* prob, int device, uint32_t 
       for (int k = 0; k < 9; ++k) dm.Rp[i][k] = mo.Rp[9 * i + k];
       pack_body_inertia(&mo, i, dm.I6[i]);
     }
+    if (!build_slot_tables(dm)) { ddp_hip_destroy(ctx); return DDP_HIP_E_UNSUPPORTED; }
   }
   CTX_TRY(hipMalloc(&ctx->model_d, sizeof(DevModel)));
   CTX_TRY(hipMemcpy(ctx->model_d, &dm, sizeof(DevModel), hipMemcpyHostToDevice));

@@ -23,6 +23,13 @@ struct DevModel {
   double Rp[DDP_MAXJ][9];
   double pp[DDP_MAXJ][3];
   double I6[DDP_MAXJ][21];  // body spatial inertia, packed lower triangle (row-major: (r,c), c<=r at r(r+1)/2+c)
+  // small-state traversal tables (ctx.hip:build_slot_tables): a joint's running sum lives in one of a few slots
+  int32_t has_child[DDP_MAXJ];      // joint has at least one child
+  int32_t first_contrib[DDP_MAXJ];  // joint is the largest-index child of its parent (contributes first, leaf->root)
+  int32_t last_child[DDP_MAXJ];     // joint is the largest-index child of its parent (read last, root->leaf)
+  int32_t slot_up[DDP_MAXJ];        // slot of the joint's accumulator in the leaf->root pass (-1: leaf)
+  int32_t slot_down[DDP_MAXJ];      // slot of the joint's value in the root->leaf pass (-1: leaf)
+  int32_t n_slots;
   // constraint chain
   int32_t eq_kind, eq_advance, frame_joint, first_order_fd, fd_mode, pad_;
   double frame_off[3];

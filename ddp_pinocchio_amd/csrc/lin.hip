@@ -241,24 +241,44 @@ __global__ __launch_bounds__(LBS) void lin_offdiag_kernel(LinParams p) {
 
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
-  double f1[2 * NJ];
+  // PAIRS == 3 keeps no private copy of x, u or f(x+dx): the control is read through a functor and the output
+  // rows are formed on the fly from the accelerations
+  double f1[PAIRS == 3 ? 1 : 2 * NJ], qdd[PAIRS == 3 ? NJ : 1];
+  const double* xg = p.x + ((int64_t)b * (T + 1) + t) * n;
+  const double* ug = p.u + ((int64_t)b * T + t) * mm;
   if (valid) {
-    double x[2 * NJ], u[NJ];
-    load_xu<NJ>(p, b, t, x, u);
-    if (i < n) x[i] = x[i] + eps; else u[i - n] = u[i - n] + eps;
-    if (j < n) x[j] = x[j] + eps; else u[j - n] = u[j - n] + eps;
-    if (PAIRS == 2) {
-      const int cfg = i < nv ? 1 + i : 0;
-      rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
-    } else if (PAIRS == 3) {
+    if (PAIRS == 3) {
       const int cfg = i < nv ? 1 + i : 0;
       const int vcfg = i < nv ? nv + 1 + i : (i < 2 * nv ? 1 + (i - nv) : 0);
-      rbd::eval_f_ucached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE,
-                              p.vcache + (bt * (2 * nv + 1) + vcfg) * (int64_t)nv * rbd::VC_STRIDE, x, u, f1);
+      const int iu = i - n, ju = j - n;
+      rbd::aba_u_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE,
+                            p.vcache + (bt * (2 * nv + 1) + vcfg) * (int64_t)nv * rbd::VC_STRIDE,
+                            [&](int k) { double v = ug[k]; if (k == iu) v = v + eps; if (k == ju) v = v + eps; return v; }, qdd);
     } else {
-      rbd::eval_f<NJ>(m, x, u, f1);
+      double x[2 * NJ], u[NJ];
+      load_xu<NJ>(p, b, t, x, u);
+      if (i < n) x[i] = x[i] + eps; else u[i - n] = u[i - n] + eps;
+      if (j < n) x[j] = x[j] + eps; else u[j - n] = u[j - n] + eps;
+      if (PAIRS == 2) {
+        const int cfg = i < nv ? 1 + i : 0;
+        rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
+      } else {
+        rbd::eval_f<NJ>(m, x, u, f1);
+      }
     }
   }
+  // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
+  auto f1_at = [&](int k) -> double {
+    if (PAIRS != 3) return f1[k];
+    if (k < nv) {
+      const double xq = k == i ? xg[k] + eps : xg[k];
+      const double xv = (nv + k) == i ? xg[nv + k] + eps : xg[nv + k];
+      const double vo = m.dt * xv;
+      return xq + vo;
+    }
+    const double xv = k == i ? xg[k] + eps : xg[k];
+    return xv + qdd[k - nv] * m.dt;
+  };
 
   // Output stage.  Each stencil point owns one 76-double column of a tensor (and reads five more columns);
   // done lane-per-point that is 64 scattered 8-byte accesses per instruction.  Instead the wave transposes the
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(LBS) void lin_offdiag_kernel(LinParams p) {
   for (int c0 = 0; c0 < n; c0 += CH) {
 #pragma unroll
     for (int q = 0; q < CH; ++q)
-      if (c0 + q < n) s_f[q][lane] = f1[c0 + q];
+      if (c0 + q < n && valid) s_f[q][lane] = f1_at(c0 + q);
     __syncthreads();
     const int k = c0 + kk;
     for (int r = 0; r < LBS / EPI; ++r) {

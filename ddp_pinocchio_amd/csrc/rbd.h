@@ -578,34 +578,42 @@ __device__ void aba_vpart_cached(const DevModel& m, const double* __restrict__ q
   }
 }
 
-// passes 2 and 3 of aba_vu_cached for a new tau
-template <int NJ>
-__device__ void aba_u_cached(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc, const double* tau,
+// passes 2 and 3 of aba_vu_cached for a new tau, with O(tree width) private state: the per-joint sums live in a few
+// slots (DevModel::slot_up / slot_down) instead of per-joint arrays; the additions happen in exactly the order of
+// aba_vu_cached (a joint's bias force starts from its cached value when its largest-index child contributes).
+// tau(i) is supplied by a functor so that the caller does not need a private copy of the control vector.
+constexpr int MAX_SLOTS = 8;
+template <int NJ, typename TauFn>
+__device__ void aba_u_cached(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc, TauFn tau,
                              double* qdd) {
   const int N = m.nv;
-  double pA[NJ][6], uu[NJ];
-  for (int i = 0; i < N; ++i)
-    for (int k = 0; k < 6; ++k) pA[i][k] = vc[i * VC_STRIDE + 6 + k];
+  double slot[MAX_SLOTS][6], uu[NJ];
   for (int i = N - 1; i >= 0; --i) {
     const double* E = qc + i * QC_STRIDE;
     const double* r = E + 9;
     const double* U = E + 12;
     const double dinv = E[18];
+    const double* pA0 = vc + i * VC_STRIDE + 6;
     const double* Iac = vc + i * VC_STRIDE + 12;
     const double* a = m.axis[i];
     const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    double pAi[6];
+    if (m.has_child[i]) { const double* sl = slot[m.slot_up[i]]; for (int k = 0; k < 6; ++k) pAi[k] = sl[k]; }
+    else { for (int k = 0; k < 6; ++k) pAi[k] = pA0[k]; }
     double sp = 0;
-    for (int k = 0; k < 3; ++k) sp += a[k] * pA[i][o + k];
-    uu[i] = tau[i] - sp;
+    for (int k = 0; k < 3; ++k) sp += a[k] * pAi[o + k];
+    const double ui = tau(i) - sp;
+    uu[i] = ui;
     const int par = m.parent[i];
     if (par >= 0) {
       double pa[6], fp[6];
-      for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[k] * (uu[i] * dinv);
+      for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
       xform_force_T(E, r, pa, fp);
-      for (int k = 0; k < 6; ++k) pA[par][k] += fp[k];
+      double* sl = slot[m.slot_up[par]];
+      if (m.first_contrib[i]) { const double* pp0 = vc + par * VC_STRIDE + 6; for (int k = 0; k < 6; ++k) sl[k] = pp0[k] + fp[k]; }
+      else { for (int k = 0; k < 6; ++k) sl[k] += fp[k]; }
     }
   }
-  double (*acc)[6] = pA;   // pass 3 reuses the storage of the (now dead) bias forces
   for (int i = 0; i < N; ++i) {
     const double* E = qc + i * QC_STRIDE;
     const double* r = E + 9;
@@ -614,7 +622,7 @@ __device__ void aba_u_cached(const DevModel& m, const double* __restrict__ qc, c
     const double* cb = vc + i * VC_STRIDE;
     double ap[6];
     const int par = m.parent[i];
-    if (par >= 0) xform_motion(E, r, acc[par], ap);
+    if (par >= 0) xform_motion(E, r, slot[m.slot_down[par]], ap);
     else {
       const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
       xform_motion(E, r, a0, ap);
@@ -623,10 +631,13 @@ __device__ void aba_u_cached(const DevModel& m, const double* __restrict__ qc, c
     for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; s += U[k] * ap[k]; }
     const double qd = (uu[i] - s) * dinv;
     qdd[i] = qd;
-    const double* a = m.axis[i];
-    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-    for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
-    acc[i][o] += a[0] * qd; acc[i][o + 1] += a[1] * qd; acc[i][o + 2] += a[2] * qd;
+    if (m.has_child[i]) {
+      const double* a = m.axis[i];
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      double* sl = slot[m.slot_down[i]];
+      for (int k = 0; k < 6; ++k) sl[k] = ap[k];
+      sl[o] += a[0] * qd; sl[o + 1] += a[1] * qd; sl[o + 2] += a[2] * qd;
+    }
   }
 }
 
@@ -635,7 +646,7 @@ __device__ void eval_f_ucached(const DevModel& m, const double* __restrict__ qc,
                                const double* u, double* x_out) {
   const int nv = m.nv;
   double acc[NJ];
-  aba_u_cached<NJ>(m, qc, vc, u, acc);
+  aba_u_cached<NJ>(m, qc, vc, [&](int i) { return u[i]; }, acc);
   for (int i = 0; i < nv; ++i) {
     const double vo = m.dt * x[nv + i];
     x_out[i] = x[i] + vo;
