@@ -402,22 +402,16 @@ BwdParams make_params(ddp_hip_ctx* ctx) {
   return p;
 }
 
-template <int NC, int MC, bool FAST>
+template <int NC, int MC>
 int launch_sweep(ddp_hip_ctx* ctx, const BwdParams& p, size_t lds_a, size_t lds_g) {
   const Dims& d = ctx->d;
   hipLaunchKernelGGL(bwd_init, dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p);
   for (int64_t t = d.T - 1; t >= 0; --t) {
     prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE);
-    if constexpr (FAST)
-      hipLaunchKernelGGL((bwd_assemble_fast<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BSF), lds_a, ctx->stream, p, t);
-    else
-      hipLaunchKernelGGL((bwd_assemble<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BS), lds_a, ctx->stream, p, t);
+    hipLaunchKernelGGL((bwd_assemble<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BS), lds_a, ctx->stream, p, t);
     prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE);
     prof_begin(ctx, DDP_HIP_K_BWD_GAINS);
-    if constexpr (FAST)
-      hipLaunchKernelGGL((bwd_gains_fast<NC, MC>), dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p, t);
-    else
-      hipLaunchKernelGGL((bwd_gains<NC, MC>), dim3((unsigned)d.batch), dim3(BS), lds_g, ctx->stream, p, t);
+    hipLaunchKernelGGL((bwd_gains<NC, MC>), dim3((unsigned)d.batch), dim3(BS), lds_g, ctx->stream, p, t);
     prof_end(ctx, DDP_HIP_K_BWD_GAINS);
   }
   HIP_TRY(hipGetLastError());
@@ -520,13 +514,12 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
   bool any_restart = false;
   int rc = DDP_HIP_OK;
   for (int64_t attempt = 0;; ++attempt) {
-    const bool generic = getenv("DDP_HIP_GENERIC_BWD") != nullptr;   // A/B switch for development
-    const bool fused = getenv("DDP_HIP_FUSED_BWD") != nullptr;     // previous structure (dense terms inside the streaming kernel)
-    if (d.n == 76 && d.m == 38 && !generic && !fused) rc = launch_sweep_split<76, 38>(ctx, p);
-    else if (d.n == 76 && d.m == 38 && !generic) rc = launch_sweep<76, 38, true>(ctx, p, lds_a, lds_g);
-    else if (d.n == 76 && d.m == 38) rc = launch_sweep<76, 38, false>(ctx, p, lds_a, lds_g);
-    else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6, false>(ctx, p, lds_a, lds_g);
-    else rc = launch_sweep<0, 0, false>(ctx, p, lds_a, lds_g);
+    // the Talos-like shape runs the split K3 / K4 kernels; every other shape (and DDP_HIP_GENERIC_BWD=1, kept for
+    // cross-checking the two implementations against each other) the run-time-shaped pair
+    const bool generic = getenv("DDP_HIP_GENERIC_BWD") != nullptr;
+    if (d.n == 76 && d.m == 38 && !generic) rc = launch_sweep_split<76, 38>(ctx, p);
+    else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6>(ctx, p, lds_a, lds_g);
+    else rc = launch_sweep<0, 0>(ctx, p, lds_a, lds_g);
     if (rc != DDP_HIP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(status.data(), ctx->status_d, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -203,7 +203,7 @@ __global__ void lin_diag_kernel(LinParams p) {
 // ABA).  PAIRS = 2: (q or v, v): the q-dependent part comes from the q-cache.  PAIRS = 3: (q, v or u; u): only tau
 // differs from a cached (q, v) pair, the evaluation is the force / acceleration passes alone.
 template <int NJ, int PAIRS>
-__global__ __launch_bounds__(LBS) void lin_offdiag_kernel(LinParams p) {
+__global__ __launch_bounds__(LBS, (PAIRS == 1 || PAIRS == 0 ? 4 : 5)) void lin_offdiag_kernel(LinParams p) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t T = p.d.T;
   const int n = (int)p.d.n, mm = (int)p.d.m;

@@ -166,70 +166,83 @@ __device__ __forceinline__ double pendulum_acc(const DevModel& m, double q, doub
 }
 
 // Articulated-body algorithm.  NJ = compile-time bound on the joint count (sizes the per-thread state).
+// Per-joint private state: E | r | cb | pA0 | U | 1/D | u (32 doubles); the articulated inertias and the running
+// vectors of the three tree passes live in a few slots (DevModel::slot_up / slot_down), allocated on the host so
+// that every sum is formed in the order of the textbook loop (a parent's accumulator starts from its own value when
+// its largest-index child contributes).
 template <int NJ>
 __device__ void aba_tree(const DevModel& m, const double* q, const double* v, const double* tau, double* qdd) {
   const int N = m.nv;
-  double E[NJ][9], R[NJ][3], cb[NJ][6], pA[NJ][6], IA[NJ][21], U[NJ][6], Dinv[NJ], uu[NJ];
-  {
-    double vel[NJ][6];
-    for (int i = 0; i < N; ++i) {
-      joint_placement(m, i, q[i], E[i], R[i]);
-      const double* a = m.axis[i];
-      double vJ[6] = {0, 0, 0, 0, 0, 0};
-      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-      vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
-      const int par = m.parent[i];
-      if (par >= 0) xform_motion(E[i], R[i], vel[par], vel[i]);
-      else { for (int k = 0; k < 6; ++k) vel[i][k] = 0.0; }
-      for (int k = 0; k < 6; ++k) vel[i][k] += vJ[k];
-      crm(vel[i], vJ, cb[i]);
-      for (int k = 0; k < 21; ++k) IA[i][k] = m.I6[i][k];
-      double Iv[6];
-      sym6_mv(IA[i], vel[i], Iv);
-      crf(vel[i], Iv, pA[i]);
-    }
+  double E[NJ][9], R[NJ][3], cb[NJ][6], pA0[NJ][6], U[NJ][6], Dinv[NJ], uu[NJ];
+  double slot[8][6], islot[8][21];
+  for (int i = 0; i < N; ++i) {
+    joint_placement(m, i, q[i], E[i], R[i]);
+    const double* a = m.axis[i];
+    double vJ[6] = {0, 0, 0, 0, 0, 0}, vel[6];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+    const int par = m.parent[i];
+    if (par >= 0) xform_motion(E[i], R[i], slot[m.slot_down[par]], vel);
+    else { for (int k = 0; k < 6; ++k) vel[k] = 0.0; }
+    for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+    if (m.has_child[i]) { double* sl = slot[m.slot_down[i]]; for (int k = 0; k < 6; ++k) sl[k] = vel[k]; }
+    crm(vel, vJ, cb[i]);
+    double Iv[6];
+    sym6_mv(m.I6[i], vel, Iv);
+    crf(vel, Iv, pA0[i]);
   }
   for (int i = N - 1; i >= 0; --i) {
     const double* a = m.axis[i];
     const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-    double d = 0, sp = 0;
-    for (int r = 0; r < 6; ++r) {
-      const double s = IA[i][sidx(r, o)] * a[0] + IA[i][sidx(r, o + 1)] * a[1] + IA[i][sidx(r, o + 2)] * a[2];
-      U[i][r] = s;
+    double IA[21], pAi[6];
+    if (m.has_child[i]) {
+      const int su = m.slot_up[i];
+      for (int k = 0; k < 21; ++k) IA[k] = islot[su][k];
+      for (int k = 0; k < 6; ++k) pAi[k] = slot[su][k];
+    } else {
+      for (int k = 0; k < 21; ++k) IA[k] = m.I6[i][k];
+      for (int k = 0; k < 6; ++k) pAi[k] = pA0[i][k];
     }
-    for (int k = 0; k < 3; ++k) { d += a[k] * U[i][o + k]; sp += a[k] * pA[i][o + k]; }
+    double d = 0, sp = 0;
+    for (int r = 0; r < 6; ++r) U[i][r] = IA[sidx(r, o)] * a[0] + IA[sidx(r, o + 1)] * a[1] + IA[sidx(r, o + 2)] * a[2];
+    for (int k = 0; k < 3; ++k) { d += a[k] * U[i][o + k]; sp += a[k] * pAi[o + k]; }
     Dinv[i] = 1.0 / d;
     uu[i] = tau[i] - sp;
     const int par = m.parent[i];
     if (par >= 0) {
       double Ia[21], pa[6], Iac[6], fp[6];
       for (int r = 0; r < 6; ++r)
-        for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[i][sidx(r, c)] - U[i][r] * U[i][c] * Dinv[i];
+        for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[sidx(r, c)] - U[i][r] * U[i][c] * Dinv[i];
       sym6_mv(Ia, cb[i], Iac);
-      for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[i][k] * (uu[i] * Dinv[i]);
-      add_xtix(E[i], R[i], Ia, IA[par]);
+      for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[i][k] * (uu[i] * Dinv[i]);
+      const int sp_ = m.slot_up[par];
+      if (m.first_contrib[i]) {
+        for (int k = 0; k < 21; ++k) islot[sp_][k] = m.I6[par][k];
+        for (int k = 0; k < 6; ++k) slot[sp_][k] = pA0[par][k];
+      }
+      add_xtix(E[i], R[i], Ia, islot[sp_]);
       xform_force_T(E[i], R[i], pa, fp);
-      for (int k = 0; k < 6; ++k) pA[par][k] += fp[k];
+      for (int k = 0; k < 6; ++k) slot[sp_][k] += fp[k];
     }
   }
-  {
-    double acc[NJ][6];
-    for (int i = 0; i < N; ++i) {
-      double ap[6];
-      const int par = m.parent[i];
-      if (par >= 0) xform_motion(E[i], R[i], acc[par], ap);
-      else {
-        const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-        xform_motion(E[i], R[i], a0, ap);
-      }
-      double s = 0;
-      for (int k = 0; k < 6; ++k) { ap[k] += cb[i][k]; s += U[i][k] * ap[k]; }
-      const double qd = (uu[i] - s) * Dinv[i];
-      qdd[i] = qd;
+  for (int i = 0; i < N; ++i) {
+    double ap[6];
+    const int par = m.parent[i];
+    if (par >= 0) xform_motion(E[i], R[i], slot[m.slot_down[par]], ap);
+    else {
+      const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+      xform_motion(E[i], R[i], a0, ap);
+    }
+    double s = 0;
+    for (int k = 0; k < 6; ++k) { ap[k] += cb[i][k]; s += U[i][k] * ap[k]; }
+    const double qd = (uu[i] - s) * Dinv[i];
+    qdd[i] = qd;
+    if (m.has_child[i]) {
       const double* a = m.axis[i];
       const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-      for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
-      acc[i][o] += a[0] * qd; acc[i][o + 1] += a[1] * qd; acc[i][o + 2] += a[2] * qd;
+      double* sl = slot[m.slot_down[i]];
+      for (int k = 0; k < 6; ++k) sl[k] = ap[k];
+      sl[o] += a[0] * qd; sl[o + 1] += a[1] * qd; sl[o + 2] += a[2] * qd;
     }
   }
 }
@@ -331,26 +344,25 @@ __device__ void aba_qpart(const DevModel& m, const double* q, double* __restrict
 
 template <int NJ>
 __device__ void aba_vu_cached(const DevModel& m, const double* __restrict__ qc, const double* v, const double* tau, double* qdd) {
+  // per-joint private state: cb | pA0 (12 doubles); the running sums of the tree passes live in a few slots
   const int N = m.nv;
-  double cb[NJ][6], pA[NJ][6], uu[NJ];
-  {
-    double vel[NJ][6];
-    for (int i = 0; i < N; ++i) {
-      const double* E = qc + i * QC_STRIDE;
-      const double* r = E + 9;
-      const double* a = m.axis[i];
-      double vJ[6] = {0, 0, 0, 0, 0, 0};
-      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-      vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
-      const int par = m.parent[i];
-      if (par >= 0) xform_motion(E, r, vel[par], vel[i]);
-      else { for (int k = 0; k < 6; ++k) vel[i][k] = 0.0; }
-      for (int k = 0; k < 6; ++k) vel[i][k] += vJ[k];
-      crm(vel[i], vJ, cb[i]);
-      double Iv[6];
-      sym6_mv(m.I6[i], vel[i], Iv);
-      crf(vel[i], Iv, pA[i]);
-    }
+  double cbp[NJ][12], uu[NJ], slot[8][6];
+  for (int i = 0; i < N; ++i) {
+    const double* E = qc + i * QC_STRIDE;
+    const double* r = E + 9;
+    const double* a = m.axis[i];
+    double vJ[6] = {0, 0, 0, 0, 0, 0}, vel[6];
+    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+    const int par = m.parent[i];
+    if (par >= 0) xform_motion(E, r, slot[m.slot_down[par]], vel);
+    else { for (int k = 0; k < 6; ++k) vel[k] = 0.0; }
+    for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+    if (m.has_child[i]) { double* sl = slot[m.slot_down[i]]; for (int k = 0; k < 6; ++k) sl[k] = vel[k]; }
+    crm(vel, vJ, cbp[i]);
+    double Iv[6];
+    sym6_mv(m.I6[i], vel, Iv);
+    crf(vel, Iv, cbp[i] + 6);
   }
   for (int i = N - 1; i >= 0; --i) {
     const double* E = qc + i * QC_STRIDE;
@@ -360,40 +372,46 @@ __device__ void aba_vu_cached(const DevModel& m, const double* __restrict__ qc, 
     const double* Ia = E + 19;
     const double* a = m.axis[i];
     const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+    double pAi[6];
+    if (m.has_child[i]) { const double* sl = slot[m.slot_up[i]]; for (int k = 0; k < 6; ++k) pAi[k] = sl[k]; }
+    else { for (int k = 0; k < 6; ++k) pAi[k] = cbp[i][6 + k]; }
     double sp = 0;
-    for (int k = 0; k < 3; ++k) sp += a[k] * pA[i][o + k];
-    uu[i] = tau[i] - sp;
+    for (int k = 0; k < 3; ++k) sp += a[k] * pAi[o + k];
+    const double ui = tau[i] - sp;
+    uu[i] = ui;
     const int par = m.parent[i];
     if (par >= 0) {
       double pa[6], Iac[6], fp[6];
-      sym6_mv(Ia, cb[i], Iac);
-      for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + Iac[k] + U[k] * (uu[i] * dinv);
+      sym6_mv(Ia, cbp[i], Iac);
+      for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
       xform_force_T(E, r, pa, fp);
-      for (int k = 0; k < 6; ++k) pA[par][k] += fp[k];
+      double* sl = slot[m.slot_up[par]];
+      if (m.first_contrib[i]) { for (int k = 0; k < 6; ++k) sl[k] = cbp[par][6 + k] + fp[k]; }
+      else { for (int k = 0; k < 6; ++k) sl[k] += fp[k]; }
     }
   }
-  {
-    double acc[NJ][6];
-    for (int i = 0; i < N; ++i) {
-      const double* E = qc + i * QC_STRIDE;
-      const double* r = E + 9;
-      const double* U = E + 12;
-      const double dinv = E[18];
-      double ap[6];
-      const int par = m.parent[i];
-      if (par >= 0) xform_motion(E, r, acc[par], ap);
-      else {
-        const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-        xform_motion(E, r, a0, ap);
-      }
-      double s = 0;
-      for (int k = 0; k < 6; ++k) { ap[k] += cb[i][k]; s += U[k] * ap[k]; }
-      const double qd = (uu[i] - s) * dinv;
-      qdd[i] = qd;
+  for (int i = 0; i < N; ++i) {
+    const double* E = qc + i * QC_STRIDE;
+    const double* r = E + 9;
+    const double* U = E + 12;
+    const double dinv = E[18];
+    double ap[6];
+    const int par = m.parent[i];
+    if (par >= 0) xform_motion(E, r, slot[m.slot_down[par]], ap);
+    else {
+      const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+      xform_motion(E, r, a0, ap);
+    }
+    double s = 0;
+    for (int k = 0; k < 6; ++k) { ap[k] += cbp[i][k]; s += U[k] * ap[k]; }
+    const double qd = (uu[i] - s) * dinv;
+    qdd[i] = qd;
+    if (m.has_child[i]) {
       const double* a = m.axis[i];
       const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-      for (int k = 0; k < 6; ++k) acc[i][k] = ap[k];
-      acc[i][o] += a[0] * qd; acc[i][o + 1] += a[1] * qd; acc[i][o + 2] += a[2] * qd;
+      double* sl = slot[m.slot_down[i]];
+      for (int k = 0; k < 6; ++k) sl[k] = ap[k];
+      sl[o] += a[0] * qd; sl[o + 1] += a[1] * qd; sl[o + 2] += a[2] * qd;
     }
   }
 }
