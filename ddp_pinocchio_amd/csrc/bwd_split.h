@@ -112,7 +112,13 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
 }
 
 // D = [f_x f_u]^T V_xx [f_x f_u] (blocks xx, ux, uu) for timestep td, with V_xx already in s_VW[0 .. N*N).
-// LDS: s_VW (N*(N+M) doubles, V_xx then W = V_xx F), s_F (N*(N+M) doubles).  All BSR lanes take part.
+// LDS: s_VW (N*(N+M) doubles: V_xx, then W = V_xx F), s_F (N*(N+M) doubles).  All BSR lanes take part.
+// This is the one genuinely dense product of the step (3.3 MFLOP per instance and step); it runs on the FP64 matrix
+// cores: v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wave at a time, operands read from LDS.
+// Lane l feeds A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15]; result register r of lane l is
+// D[row = (l >> 4) + 4 r][col = l & 15].  Rows / columns beyond the matrix are fed zeros.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 template <int N, int M>
 __device__ __forceinline__ void dense_product(const BwdParams& p, int b, int64_t td, double* s_VW, double* s_F) {
   constexpr int n = N, m = M, NM = N + M;
@@ -133,73 +139,71 @@ __device__ __forceinline__ void dense_product(const BwdParams& p, int b, int64_t
     for (int i = tid; i < n * m / 2; i += BSR) d[n * n / 2 + i] = c[i];
   }
   __syncthreads();
-  // W = V_xx F: 2 x 2 register tiles, two l per step (16-byte LDS reads)
-  constexpr int TR = N / 2, TC = NM / 2, NT_W = TR * TC;          // 38 x 57 tiles
-  constexpr int WI = (NT_W + BSR - 1) / BSR;                      // 5
-  double w[WI][4];
+  const int wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  constexpr int NW = BSR / 64;
+  constexpr int KS = N / 4;                                   // 19 k-steps of 4
+  static_assert(N % 4 == 0, "k-steps of 4");
+  constexpr int MT_V = (N + 15) / 16, NT = (NM + 15) / 16;    // 5 row tiles of V, 8 column tiles of F
+  // W = V_xx F  (76 x 114): tiles (mt, nt); results kept in registers until every wave is done reading V_xx
+  constexpr int W_TILES = MT_V * NT, W_PER_WAVE = (W_TILES + NW - 1) / NW;   // 40 tiles, 5 per wave
+  f64x4 wacc[W_PER_WAVE];
 #pragma unroll
-  for (int it = 0; it < WI; ++it) {
-    const int tile = tid + it * BSR;
-    const int tr = tile % TR, tc = (tile / TR) < TC ? tile / TR : TC - 1;
-    const double* vp = s_VW + 2 * tr;
-    const double* f0 = s_F + (2 * tc) * n;
-    const double* f1 = f0 + n;
-    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll 2
-    for (int l = 0; l < n; l += 2) {
-      const f64x2 v0 = *reinterpret_cast<const f64x2*>(vp + l * n);        // V(r0:r0+2, l)
-      const f64x2 v1 = *reinterpret_cast<const f64x2*>(vp + (l + 1) * n);  // V(r0:r0+2, l+1)
-      const f64x2 g0 = *reinterpret_cast<const f64x2*>(f0 + l);            // F(l:l+2, c0)
-      const f64x2 g1 = *reinterpret_cast<const f64x2*>(f1 + l);            // F(l:l+2, c0+1)
-      a00 += v0.x * g0.x; a00 += v1.x * g0.y;
-      a10 += v0.y * g0.x; a10 += v1.y * g0.y;
-      a01 += v0.x * g1.x; a01 += v1.x * g1.y;
-      a11 += v0.y * g1.x; a11 += v1.y * g1.y;
+  for (int it = 0; it < W_PER_WAVE; ++it) {
+    const int tile = wave + it * NW;
+    const int mt = tile % MT_V, nt = (tile / MT_V) % NT;
+    const int row = 16 * mt + l15, col = 16 * nt + l15;
+    const bool rok = row < n, cok = col < NM;
+    const double* va = s_VW + (rok ? row : 0) + l4 * n;       // V(row, 4 s + l4)
+    const double* fb = s_F + (cok ? col : 0) * n + l4;        // F(4 s + l4, col)
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double av = rok ? va[4 * s * n] : 0.0;
+      const double bv = cok ? fb[4 * s] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
-    w[it][0] = a00; w[it][1] = a10; w[it][2] = a01; w[it][3] = a11;
+    wacc[it] = acc;
   }
-  __syncthreads();   // every lane is done reading V_xx: W may overwrite it
+  __syncthreads();   // every wave is done reading V_xx: W may overwrite it
 #pragma unroll
-  for (int it = 0; it < WI; ++it) {
-    const int tile = tid + it * BSR;
-    if (tile < NT_W) {
-      const int tr = tile % TR, tc = tile / TR;
-      double* dst = s_VW + 2 * tr + (2 * tc) * n;
-      dst[0] = w[it][0]; dst[1] = w[it][1]; dst[n] = w[it][2]; dst[n + 1] = w[it][3];
+  for (int it = 0; it < W_PER_WAVE; ++it) {
+    const int tile = wave + it * NW;
+    if (tile < W_TILES) {
+      const int mt = tile % MT_V, nt = tile / MT_V;
+      const int col = 16 * nt + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + l4 + 4 * r;
+        if (row < n && col < NM) s_VW[row + col * n] = wacc[it][r];
+      }
     }
   }
   __syncthreads();
-  // D(j, c) = sum_k F(k, j) W(k, c) for the blocks xx (j<N, c<N), ux (j>=N, c<N), uu (j>=N, c>=N); 2 x 2 tiles
-  constexpr int TXX = (N / 2) * (N / 2), TUX = (M / 2) * (N / 2), TUU = (M / 2) * (M / 2), NT_D = TXX + TUX + TUU;
-  for (int tile = tid; tile < NT_D; tile += BSR) {
-    int j0, cc0;
-    if (tile < TXX) { j0 = 2 * (tile % (N / 2)); cc0 = 2 * (tile / (N / 2)); }
-    else if (tile < TXX + TUX) { const int q = tile - TXX; j0 = N + 2 * (q % (M / 2)); cc0 = 2 * (q / (M / 2)); }
-    else { const int q = tile - TXX - TUX; j0 = N + 2 * (q % (M / 2)); cc0 = N + 2 * (q / (M / 2)); }
-    const double* f0 = s_F + j0 * n;
-    const double* f1 = f0 + n;
-    const double* w0 = s_VW + cc0 * n;
-    const double* w1 = w0 + n;
-    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll 2
-    for (int k = 0; k < n; k += 2) {
-      const f64x2 g0 = *reinterpret_cast<const f64x2*>(f0 + k);
-      const f64x2 g1 = *reinterpret_cast<const f64x2*>(f1 + k);
-      const f64x2 h0 = *reinterpret_cast<const f64x2*>(w0 + k);
-      const f64x2 h1 = *reinterpret_cast<const f64x2*>(w1 + k);
-      a00 += g0.x * h0.x; a00 += g0.y * h0.y;
-      a10 += g1.x * h0.x; a10 += g1.y * h0.y;
-      a01 += g0.x * h1.x; a01 += g0.y * h1.y;
-      a11 += g1.x * h1.x; a11 += g1.y * h1.y;
+  // D(j, c) = sum_k F(k, j) W(k, c): tiles (jt, ct) over 114 x 114, skipping those entirely inside the unused
+  // (j < N, c >= N) block
+  constexpr int JT = NT, CT = NT;
+  for (int tile = wave; tile < JT * CT; tile += NW) {
+    const int jt = tile % JT, ct = tile / JT;
+    if (16 * jt + 15 < n && 16 * ct >= n) continue;           // wave-uniform
+    const int j = 16 * jt + l15, c = 16 * ct + l15;
+    const bool jok = j < NM, cok = c < NM;
+    const double* fa = s_F + (jok ? j : 0) * n + l4;          // F(4 s + l4, j)  = A(j, k)
+    const double* wb = s_VW + (cok ? c : 0) * n + l4;         // W(4 s + l4, c)  = B(k, c)
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double av = jok ? fa[4 * s] : 0.0;
+      const double bv = cok ? wb[4 * s] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
-    if (j0 < N) {
-      Dxx[j0 + cc0 * n] = a00; Dxx[j0 + 1 + cc0 * n] = a10; Dxx[j0 + (cc0 + 1) * n] = a01; Dxx[j0 + 1 + (cc0 + 1) * n] = a11;
-    } else if (cc0 < N) {
-      const int ju = j0 - N;
-      Dux[ju + cc0 * m] = a00; Dux[ju + 1 + cc0 * m] = a10; Dux[ju + (cc0 + 1) * m] = a01; Dux[ju + 1 + (cc0 + 1) * m] = a11;
-    } else {
-      const int ju = j0 - N, cu = cc0 - N;
-      Duu[ju + cu * m] = a00; Duu[ju + 1 + cu * m] = a10; Duu[ju + (cu + 1) * m] = a01; Duu[ju + 1 + (cu + 1) * m] = a11;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jr = 16 * jt + l4 + 4 * r;                    // result row
+      if (jr >= NM || c >= NM) continue;
+      if (jr < n) { if (c < n) Dxx[jr + c * n] = acc[r]; }
+      else if (c < n) Dux[(jr - n) + c * m] = acc[r];
+      else Duu[(jr - n) + (c - n) * m] = acc[r];
     }
   }
 }
@@ -253,7 +257,6 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   const double* eq_uu = p.eq_uu + ((int64_t)b * Etot + Eo) * m * m;
 
   constexpr int lda = M | 1, ldr = M | 1, NR = N + 1, NM = N + M;
-  constexpr int RS = 3, RQ = (M + RS - 1) / RS;
   constexpr int TJ = 6, AQ = (M + TJ - 1) / TJ;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* s_VW = smem;                         // N*NM: new V_xx, later W (dense tail)
@@ -261,11 +264,10 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   double* A = s_F;                             // lda*M   Q_uu + reg I -> Cholesky factor (lower)
   double* R = A + lda * M;                     // ldr*NR  [k | K]
   double* S = R + ldr * NR;                    // ldr*N   Q_ux
-  double* Y = S + ldr * N;                     // 2*NR    published pivot rows
-  double* s_q = Y + 2 * NR;                    // NM      Q_x | Q_u
+  double* s_q = S + ldr * N;                   // NM      Q_x | Q_u
   double* s_vx = s_q + NM;                     // N       incoming V_x
   double* s_tmp = s_vx + N;                    // emax    pe + mu eq   (ddp_bwd.ipp:46)
-  static_assert(lda * M + ldr * NR + ldr * N + 2 * NR + NM + N + 64 <= N * NM, "phase-A arrays must fit the F region");
+  static_assert(lda * M + ldr * NR + ldr * N + NM + N + 64 <= N * NM, "phase-A arrays must fit the F region");
 
   // entries of Q in the reference's order of terms (ddp_bwd.ipp:70-87): l, f^T V_xx f, multiplier terms, multiplier
   // tensors, V_x-contracted tensors
@@ -310,6 +312,13 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     return acc;
   };
 
+#ifdef DDP_RICCATI_TIMING
+  unsigned long long tk[10]; int tki = 0;
+#define RSTAMP() do { tk[tki++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RSTAMP() do {} while (0)
+#endif
+  RSTAMP();
   for (int i = tid; i < n; i += BSR) s_vx[i] = Vx[i];
   for (int i = tid; i < e; i += BSR) s_tmp[i] = pe[i] + mu * eqv[i];
   __syncthreads();
@@ -340,18 +349,14 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   __syncthreads();
 
   const double reg = p.reg[b];
-  // right-hand sides [-Q_u | -Q_ux] (:135-136) in registers: lane (rc, rs) owns rows rs, rs+3, ... of column rc
-  const int rc = tid % NR, rs = tid / NR;
-  const bool rhs_lane = tid < NR * RS;
-  double r[RQ];
+  // right-hand sides [-Q_u | -Q_ux] (:135-136): lane 256 + c owns the whole column c in registers (waves 4-5), so the
+  // substitutions need no cross-lane traffic at all; waves 0-3 carry the factorisation
+  const int rc = tid - 256;
+  const bool rhs_lane = tid >= 256 && rc < NR;
+  double r[M];
   if (rhs_lane) {
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const int l = rs + RS * q;
-      const int lc = l < m ? l : m - 1;
-      const double v = rc == 0 ? s_q[n + lc] : S[lc + (rc - 1) * ldr];
-      r[q] = l < m ? -v : 0.0;
-    }
+    for (int l = 0; l < m; ++l) r[l] = -(rc == 0 ? s_q[n + l] : S[l + (rc - 1) * ldr]);
   }
   // trailing matrix of the factorisation in registers: lane (ti, tj) owns row ti, columns tj, tj+6, ... <= ti
   const int ti = tid % M, tj = tid / M;
@@ -364,25 +369,19 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   }
   if (a_lane && tj == 0) A[ti] = a[0];       // raw column 0
   __syncthreads();
+  RSTAMP();
 
-  // Cholesky (lower triangle only; fail <=> pivot <= 0, :105) with the forward substitution fused in (see
-  // bwd_gains_fast); every LDS read is unconditional (clamped index + select)
+  // Cholesky (lower triangle only; fail <=> pivot <= 0, :105) with the forward substitution fused in: column k of L is
+  // final after step k, so y_k = r_k / L_kk and r_l -= L_lk y_k (l > k) ride along with the trailing update.  Per
+  // entry the updates arrive in ascending k: the order of Eigen's unblocked LLT and of its row-wise substitution.
   bool failed = false;
+#pragma unroll
   for (int k = 0; k < m; ++k) {
     const double piv = A[k + k * lda];
     if (piv <= 0.0) { failed = true; break; }
     const double dk = sqrt(piv);
     if (a_lane && tj == 0 && ti > k) A[ti + k * lda] = A[ti + k * lda] / dk;
-    if (rhs_lane && rs == k % RS) {
-      const int qk = k / RS;
-      double rk = 0.0;
-#pragma unroll
-      for (int q = 0; q < RQ; ++q) rk = q == qk ? r[q] : rk;
-      rk = rk / dk;
-#pragma unroll
-      for (int q = 0; q < RQ; ++q) r[q] = q == qk ? rk : r[q];
-      Y[(k & 1) * NR + rc] = rk;
-    }
+    if (rhs_lane) r[k] = r[k] / dk;
     __syncthreads();
     const double* Lk = A + k * lda;
     if (a_lane) {
@@ -394,22 +393,11 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
         a[q] = (j > k && j <= ti) ? a[q] - lik * ljk : a[q];
       }
       const int k1 = k + 1;
-      if (k1 < m && tj == k1 % TJ && ti >= k1) {
-        const int q1 = k1 / TJ;
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q < AQ; ++q) v = q == q1 ? a[q] : v;
-        A[ti + k1 * lda] = v;
-      }
+      if (k1 < m && tj == k1 % TJ && ti >= k1) A[ti + k1 * lda] = a[k1 / TJ];   // raw column k+1, final after this update
     }
     if (rhs_lane) {
-      const double yk = Y[(k & 1) * NR + rc];
 #pragma unroll
-      for (int q = 0; q < RQ; ++q) {
-        const int l = rs + RS * q;
-        const double llk = Lk[l < m ? l : m - 1];
-        r[q] = (l > k && l < m) ? r[q] - llk * yk : r[q];
-      }
+      for (int l = k + 1; l < m; ++l) r[l] -= Lk[l] * r[k];
     }
     if (tid == k) A[k + k * lda] = dk;
     __syncthreads();
@@ -427,40 +415,26 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     }
     return;
   }
-  for (int k = m - 1; k >= 0; --k) {          // back substitution L^T x = y
-    if (rhs_lane && rs == k % RS) {
-      const double dk = A[k + k * lda];
-      const int qk = k / RS;
-      double rk = 0.0;
+  RSTAMP();
+  // back substitution L^T x = y, column oriented, entirely inside each right-hand-side lane
+  if (rhs_lane) {
 #pragma unroll
-      for (int q = 0; q < RQ; ++q) rk = q == qk ? r[q] : rk;
-      rk = rk / dk;
+    for (int k = m - 1; k >= 0; --k) {
+      r[k] = r[k] / A[k + k * lda];
 #pragma unroll
-      for (int q = 0; q < RQ; ++q) r[q] = q == qk ? rk : r[q];
-      Y[(k & 1) * NR + rc] = rk;
-    }
-    __syncthreads();
-    if (rhs_lane) {
-      const double xk = Y[(k & 1) * NR + rc];
-#pragma unroll
-      for (int q = 0; q < RQ; ++q) {
-        const int i = rs + RS * q;
-        const double lki = A[k + (i < m ? i : m - 1) * lda];
-        r[q] = i < k ? r[q] - lki * xk : r[q];
-      }
+      for (int i = 0; i < k; ++i) r[i] -= A[k + i * lda] * r[k];
+      __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 703 LDS reads (register pressure)
     }
   }
 
+  RSTAMP();
   double* fbo = p.fb_origin + bt * nx;
   const double* xt = p.x + ((int64_t)b * (T + 1) + t) * nx;
   for (int i = tid; i < nx; i += BSR) fbo[i] = xt[i];                        // :134
   if (rhs_lane) {
     double* dst = rc == 0 ? p.fb_val + bt * m : p.fb_jac + bt * m * n + (rc - 1) * m;
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const int l = rs + RS * q;
-      if (l < m) { dst[l] = r[q]; R[l + rc * ldr] = r[q]; }
-    }
+    for (int l = 0; l < m; ++l) { dst[l] = r[l]; R[l + rc * ldr] = r[l]; }
   }
   __syncthreads();
 
@@ -502,5 +476,11 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     return;
   }
   __syncthreads();   // V_xx complete in LDS; A, R, S, Y are dead: their space becomes F
+  RSTAMP();
   dense_product<N, M>(p, b, t - 1, s_VW, s_F);
+  RSTAMP();
+#ifdef DDP_RICCATI_TIMING
+  if (b == 0 && tid == 0 && t == 5)
+    printf("riccati cycles: assemble %llu llt+fwd %llu back %llu store+vupdate %llu dense %llu\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
+#endif
 }
