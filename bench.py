@@ -148,7 +148,7 @@ def main():
                                    f"line-search alphas, {'full DDP (FD f_x,f_u + FD f_xx,f_ux,f_uu mode 2)' if full else 'tensor-free (Gauss-Newton) variant'}",
                        "mode": a.mode, "horizon": T, "seeds_per_gpu": S, "n_alpha": a.n_alpha, "parallelism": f"seeds x{world}"},
             "roofline": {"kernel": "bwd_contract (K3: V_x-contracted f_xx, f_ux, f_uu)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(S),
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": n_a},
             "phases_ms_per_step": {k: v / a.steps for k, v in phase_ms.items()},
             "kernels_ms_per_step": {"bwd_contract": ms_a / a.steps, "bwd_riccati": ms_g / a.steps, "fwd_rollout": ms_f / a.steps,
@@ -160,6 +160,16 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(S):
+    """HBM bytes per K3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 for gfx950's wide-read
+    under-count + WRITE_SIZE, separate --pmc runs: profiles/k3_traffic.json), valid for the profiled batch only"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
+        return float(rec["bytes_per_launch"]) if int(rec["batch"]) == S else None
+    except Exception:
+        return None
 
 
 def cpu_baseline(a, model):
@@ -176,7 +186,7 @@ def cpu_baseline(a, model):
     except Exception:
         path = None
     full = a.mode == "full"
-    Ts = a.cpu_sample_steps or (20 if full else a.horizon)
+    Ts = a.cpu_sample_steps or a.horizon
     o = Oracle(model, Ts, dt=0.01, c=1.0, fd_mode=2 if full else 0, lib_path=path)
     us = 0.1 * np.random.default_rng(0xDD9000 + 3000).normal(size=Ts * model.nv)
     xs = o.rollout(np.zeros(2 * model.nv), us)

@@ -312,13 +312,6 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     return acc;
   };
 
-#ifdef DDP_RICCATI_TIMING
-  unsigned long long tk[10]; int tki = 0;
-#define RSTAMP() do { tk[tki++] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define RSTAMP() do {} while (0)
-#endif
-  RSTAMP();
   for (int i = tid; i < n; i += BSR) s_vx[i] = Vx[i];
   for (int i = tid; i < e; i += BSR) s_tmp[i] = pe[i] + mu * eqv[i];
   __syncthreads();
@@ -369,7 +362,6 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   }
   if (a_lane && tj == 0) A[ti] = a[0];       // raw column 0
   __syncthreads();
-  RSTAMP();
 
   // Cholesky (lower triangle only; fail <=> pivot <= 0, :105) with the forward substitution fused in: column k of L is
   // final after step k, so y_k = r_k / L_kk and r_l -= L_lk y_k (l > k) ride along with the trailing update.  Per
@@ -415,7 +407,6 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     }
     return;
   }
-  RSTAMP();
   // back substitution L^T x = y, column oriented, entirely inside each right-hand-side lane
   if (rhs_lane) {
 #pragma unroll
@@ -427,7 +418,6 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     }
   }
 
-  RSTAMP();
   double* fbo = p.fb_origin + bt * nx;
   const double* xt = p.x + ((int64_t)b * (T + 1) + t) * nx;
   for (int i = tid; i < nx; i += BSR) fbo[i] = xt[i];                        // :134
@@ -476,11 +466,5 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     return;
   }
   __syncthreads();   // V_xx complete in LDS; A, R, S, Y are dead: their space becomes F
-  RSTAMP();
   dense_product<N, M>(p, b, t - 1, s_VW, s_F);
-  RSTAMP();
-#ifdef DDP_RICCATI_TIMING
-  if (b == 0 && tid == 0 && t == 5)
-    printf("riccati cycles: assemble %llu llt+fwd %llu back %llu store+vupdate %llu dense %llu\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
-#endif
 }

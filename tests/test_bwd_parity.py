@@ -114,3 +114,27 @@ def test_backward_max_restarts(gpu):
         with pytest.raises(capi.DdpHipError) as ei:
             ctx.backward(reg=0.0, mu=1.0, max_restarts=3)
         assert ei.value.code == capi.E_MAX_RESTARTS
+
+
+@pytest.mark.gpu
+def test_split_and_generic_kernels_agree(gpu, monkeypatch):
+    """The Talos-like shape normally runs the split K3/K4 kernels (compile-time shape, MFMA dense product); forcing
+    the run-time-shaped pair on the same inputs must give the same sweep (two implementations, one oracle)."""
+    capi = gpu
+    nv, T = 38, 5
+    e = [0] * T
+    o = _oracle(nv, T, e)
+    d, xs, us, mults = synth_sweep_inputs(T, nv, e, seed=77)
+    ref = o.backward(d, xs, mults, reg=0.0, mu=10.0)
+    worst = {}
+    for mode in ("split", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("DDP_HIP_GENERIC_BWD", "1")
+        else:
+            monkeypatch.delenv("DDP_HIP_GENERIC_BWD", raising=False)
+        with capi.Context(_spec(capi, nv, T, e, 1), flags=capi.FLAG_TRACE) as ctx:
+            upload_sweep_inputs(ctx, d, xs, us, mults, 0)
+            rc, reg, mu, restarts = ctx.backward(reg=0.0, mu=10.0)
+            assert rc == 0
+            worst[mode] = _compare_instance(ctx, 0, o, ref, T)
+    assert worst["split"] < TOL and worst["generic"] < TOL, worst
