@@ -51,9 +51,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # rehearsal knobs (development only): DDP_BENCH_BACKEND=gloo and DDP_BENCH_SINGLE_DEVICE=1 run the N > 1 code path
+    # with every rank on GPU 0 of a one-GPU box; the driver's multi-GPU runs use the defaults (nccl = RCCL, one GPU per rank)
+    backend = os.environ.get("DDP_BENCH_BACKEND", "nccl")
+    if os.environ.get("DDP_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     T, S = a.horizon, a.seeds_per_gpu
     full = a.mode == "full"
@@ -94,7 +103,7 @@ def main():
             # the one exchange step: best-cost pick over all seeds of all ranks (two 8-byte RCCL all-reduces)
             ctx.cost_seq_aug(0, mu)
             costs = ctx.download("COSTS_OLD").sum(axis=1)
-            shard.best_of(costs, [rank * S + s for s in range(S)], device="cuda")
+            shard.best_of(costs, [rank * S + s for s in range(S)], device=red_dev)
         if timed:
             phase_ms["linearize"] += (t1 - t0) * 1e3
             phase_ms["backward"] += (t2 - t1) * 1e3
@@ -118,7 +127,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
     ctx.profile_enable(False)

@@ -153,26 +153,36 @@ def test_cost_seq_aug_parity(gpu, name, T):
         assert got[T] == 0.0
 
 
-def _one_iteration_inputs(o, model, seed, mu):
+def _one_iteration_inputs(o, model, seed, mu, u_sigma, jac_sigma):
     """derivatives + a backward sweep from the oracle: inputs of the forward pass"""
-    x0, us, xs = initial_trajectory(o, model, seed=seed, u_sigma=0.3)
+    x0, us, xs = initial_trajectory(o, model, seed=seed, u_sigma=u_sigma)
     d = o.compute_derivatives(xs, us)
     rng = np.random.default_rng(seed)
     mults = o.alloc_affine(o.Etot)
     mults["origin"][:] = xs[:o.T * o.nx]
-    mults["jac"][:o.Etot * o.n] = 0.1 * rng.normal(size=o.Etot * o.n)
+    mults["jac"][:o.Etot * o.n] = jac_sigma * rng.normal(size=o.Etot * o.n)
     bw = o.backward(d, xs, mults, reg=0.0, mu=mu)
+    assert bw["restarts"] == 0, bw["restarts"]      # a well-posed sweep: the gains are meaningful
     return xs, us, d, mults, bw
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,T,fd_mode,mu", [("pendulum", 50, 2, 100.0), ("chain6", 10, 2, 100.0), ("tree38", 10, 0, 1.0)])
-def test_forward_parity(gpu, name, T, fd_mode, mu):
+@pytest.mark.parametrize("name,T,fd_mode,mu,u_sigma,jac_sigma,k_scale", [
+    ("pendulum", 50, 2, 100.0, 0.3, 0.1, 1.0),
+    ("chain6", 10, 2, 100.0, 0.05, 0.01, 1.0),
+    ("chain6", 10, 2, 100.0, 0.05, 0.01, 40.0),     # overshooting feed-forward: the line search has to halve
+    ("tree38", 10, 0, 1.0, 0.3, 0.0, 1.0),
+    ("tree38", 10, 0, 1.0, 0.3, 0.0, 30.0),
+])
+def test_forward_parity(gpu, name, T, fd_mode, mu, u_sigma, jac_sigma, k_scale):
     """Same accepted step as the reference's sequential halving, same new trajectory (ddp_fwd.ipp:9-67)."""
     capi = gpu
     model, spec, o = make(name, T, fd_mode=fd_mode)
-    xs, us, d, mults, bw = _one_iteration_inputs(o, model, 21, mu)
+    xs, us, d, mults, bw = _one_iteration_inputs(o, model, 21, mu, u_sigma, jac_sigma)
+    bw["fb"]["val"] *= k_scale
     step_ref, xs_ref, us_ref, n_evals = o.forward(xs, us, mults, bw["fb"], bw["mu"])
+    if k_scale > 1:
+        assert n_evals > 1 and step_ref < 1.0, (step_ref, n_evals)    # the case really exercises the halving
     with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
         _upload_traj(ctx, xs, us)
         ctx.upload("X_NEW", xs, 0, 1)

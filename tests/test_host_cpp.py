@@ -34,3 +34,12 @@ def test_pendulum_driver_on_gpu(gpu):
     out = subprocess.run([os.path.join(HOST, "pendulum_ddp"), "50"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "x_f:" in out.stdout
+
+
+@pytest.mark.gpu
+def test_pinocchio_driver_on_gpu(gpu):
+    """test/pinocchio_ddp.cpp shape (UR5-like arm, horizon 10, config constraint every step) through the C++ mirror"""
+    _build()
+    out = subprocess.run([os.path.join(HOST, "pinocchio_ddp"), "10", "1e4", "1e-1", "10", "30"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
