@@ -138,3 +138,57 @@ def test_split_and_generic_kernels_agree(gpu, monkeypatch):
             assert rc == 0
             worst[mode] = _compare_instance(ctx, 0, o, ref, T)
     assert worst["split"] < TOL and worst["generic"] < TOL, worst
+
+
+@pytest.mark.gpu
+def test_backward_parity_full_size(gpu):
+    """BASELINE.json's full size: Talos-like n = 76, m = 38, horizon T = 200, with all three second-order tensors
+    (1.23 GB of derivative inputs for the one instance), directly against the C oracle, plus two size-independent
+    properties of the sweep: (i) with the tensors zeroed it equals the tensor-free (Gauss-Newton) context bit for bit,
+    (ii) every instance of a batch is independent of its neighbours (same inputs -> same bits in every slot)."""
+    capi = gpu
+    nv, T = 38, 200
+    e = [0] * T
+    o = _oracle(nv, T, e)
+    d, xs, us, mults = synth_sweep_inputs(T, nv, e, seed=2024)
+    ref = o.backward(d, xs, mults, reg=0.0, mu=10.0)
+    assert ref["restarts"] == 0
+    with capi.Context(_spec(capi, nv, T, e, 2), flags=capi.FLAG_TRACE) as ctx:
+        for b in range(2):
+            upload_sweep_inputs(ctx, d, xs, us, mults, b)
+        rc, reg, mu, restarts = ctx.backward(reg=0.0, mu=10.0)
+        assert rc == 0 and not restarts.any()
+        assert _compare_instance(ctx, 0, o, ref, T) < TOL
+        K = ctx.download("FB_JAC")
+        Vxx = ctx.download("VXX_TRACE")
+        assert np.array_equal(K[0], K[1]) and np.array_equal(Vxx[0], Vxx[1])          # (ii)
+        # (i) zero tensors == tensor-free context
+        for s in ("FXX", "FUX", "FUU"):
+            ctx.fill(s, 0.0)
+        ctx.backward(reg=0.0, mu=10.0)
+        K0 = ctx.download("FB_JAC", 0, 1)[0]
+    with capi.Context(_spec(capi, nv, T, e, 1), flags=capi.FLAG_TRACE | capi.FLAG_NO_TENSORS) as ctx:
+        upload_sweep_inputs(ctx, d, xs, us, mults, 0, tensors=False)
+        ctx.backward(reg=0.0, mu=10.0)
+        Kgn = ctx.download("FB_JAC", 0, 1)[0]
+    for k in ("fxx", "fux", "fuu"):
+        d[k][:] = 0.0
+    ref0 = o.backward(d, xs, mults, reg=0.0, mu=10.0)
+    assert np.array_equal(K0, Kgn)
+    assert rel_err(Kgn, ref0["fb"]["jac"][:Kgn.size]) < TOL
+
+
+@pytest.mark.gpu
+def test_shard_best_single_rank_rccl(gpu):
+    """ddp_hip_shard_best over a one-rank RCCL communicator (the multi-rank reduction logic is covered on gloo)"""
+    import ctypes as C
+    capi = gpu
+    L = capi.lib()
+    uid = (C.c_ubyte * 128)()
+    assert L.ddp_hip_comm_unique_id(uid) == 0
+    comm = C.c_void_p()
+    assert L.ddp_hip_comm_init(uid, 0, 1, 0, C.byref(comm)) == 0
+    cost, idx = C.c_double(), C.c_int64()
+    assert L.ddp_hip_shard_best(comm, -2.5, 17, C.byref(cost), C.byref(idx)) == 0
+    assert cost.value == -2.5 and idx.value == 17
+    assert L.ddp_hip_comm_destroy(comm) == 0
