@@ -168,6 +168,7 @@ def main():
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()          # rank 0 may still be timing the CPU baseline: leave together
         dist.destroy_process_group()
 
 
