@@ -96,6 +96,25 @@ static bool build_slot_tables(DevModel& dm) {
     if (par >= 0 && dm.last_child[i]) used[dm.slot_down[par]] = false;
   }
   dm.n_slots = n_slots;
+  // level schedule + children lists
+  int level[DDP_MAXJ];
+  int nl = 0;
+  for (int i = 0; i < N; ++i) { level[i] = dm.parent[i] >= 0 ? level[dm.parent[i]] + 1 : 0; if (level[i] + 1 > nl) nl = level[i] + 1; }
+  dm.n_levels = nl;
+  dm.max_level_width = 0;
+  int pos = 0;
+  for (int L = 0; L < nl; ++L) {
+    dm.lvl_start[L] = pos;
+    for (int i = 0; i < N; ++i) if (level[i] == L) dm.lvl_joint[pos++] = i;
+    if (pos - dm.lvl_start[L] > dm.max_level_width) dm.max_level_width = pos - dm.lvl_start[L];
+  }
+  dm.lvl_start[nl] = pos;
+  pos = 0;
+  for (int i = 0; i < N; ++i) {
+    dm.child_start[i] = pos;
+    for (int c = N - 1; c > i; --c) if (dm.parent[c] == i) dm.child_list[pos++] = c;
+  }
+  dm.child_start[N] = pos;
   return n_slots <= 8;   // rbd::MAX_SLOTS
 }
 

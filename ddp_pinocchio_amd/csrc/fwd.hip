@@ -168,14 +168,18 @@ __global__ void forward_kernel(FwdParams p) {
 
 // Latency path of the same rollouts (tree models, no constraints): one 64-lane workgroup per instance, 8 lanes per
 // candidate.  The gain product K_t (x_new - x_old) is spread over the 8 lanes of a candidate (each takes every 8th
-// column of K_t, 16-byte loads of contiguous columns, then three xor-shuffles); the forward dynamics runs on the
-// first lane of each candidate with its per-joint state in LDS instead of scratch.
+// column of K_t, contiguous column loads, then three xor-shuffles); the forward dynamics keeps its per-joint state in
+// LDS and its 8 lanes walk the tree level by level (rbd::aba_tree_coop), so the legs, arms and head advance together.
 template <int NJ>
 __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
   constexpr int NC = 8, NH = 8;                      // candidates per instance, helper lanes per candidate
+  constexpr int n = 2 * NJ, nx = 2 * NJ, nu = NJ;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* aba_state = lds;                           // ABA_LDS_SLOTS * NJ * NC
-  double* s_dx = lds + rbd::ABA_LDS_SLOTS * NJ * NC; // NC * 2 NJ
+  double* s_dx = lds + rbd::ABA_LDS_SLOTS * NJ * NC; // NC * n
+  double* s_x = s_dx + NC * n;                       // NC * nx
+  double* s_u = s_x + NC * nx;                       // NC * nu
+  double* s_qdd = s_u + NC * nu;                     // NC * nu
   const int b = blockIdx.x;
   if (p.state[b] != 0) return;
   const int tid = threadIdx.x, a = tid / NH, h = tid % NH;
@@ -185,7 +189,6 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
   if (a < na && cand > 33 && h == 0) p.fw_dcost[(int64_t)b * na + a] = INFINITY;
   const double step = ldexp(1.0, -cand);
   const DevModel& m = *p.model;
-  constexpr int n = 2 * NJ, nx = 2 * NJ, nu = NJ;
   const int64_t T = p.d.T;
   const double* xo = p.x_old + (int64_t)b * (T + 1) * nx;
   const double* uo = p.u_old + (int64_t)b * T * nu;
@@ -193,16 +196,19 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
   double* uw = p.fw_u + ((int64_t)b * na + (a < na ? a : 0)) * T * nu;
   const double* cold = p.costs_old + (int64_t)b * (T + 1);
   double* dx = s_dx + a * n;
-  double x[2 * NJ], xn[2 * NJ], u[NJ];
+  double* x = s_x + a * nx;
+  double* u = s_u + a * nu;
+  double* qdd = s_qdd + a * nu;
   const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
-  if (h == 0 && live)
-    for (int i = 0; i < nx; ++i) { x[i] = x0[i]; xw[i] = x0[i]; }
+  if (live)
+    for (int i = h; i < nx; i += NH) { x[i] = x0[i]; xw[i] = x0[i]; }
   double dsum = 0.0;
+  __syncthreads();
   for (int64_t t = 0; t < T; ++t) {
     const double* k = p.fb_val + ((int64_t)b * T + t) * nu;
     const double* K = p.fb_jac + ((int64_t)b * T + t) * nu * n;
-    if (h == 0 && live)
-      for (int i = 0; i < n; ++i) dx[i] = x[i] - xo[t * nx + i];               // :45 difference(out, old, new)
+    if (live)
+      for (int i = h; i < n; i += NH) dx[i] = x[i] - xo[t * nx + i];           // :45 difference(out, old, new)
     __syncthreads();
     double acc[NJ];
 #pragma unroll
@@ -220,20 +226,28 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
       acc[i] += __shfl_xor(acc[i], 4, 64);
     }
     if (h == 0 && live) {
+      double un = 0;
 #pragma unroll
       for (int i = 0; i < nu; ++i) {
         double ui = uo[t * nu + i] + step * k[i];                               // :47-48
         ui += acc[i];                                                           // :49
         u[i] = ui;
         uw[t * nu + i] = ui;
+        un += ui * ui;
       }
-      double un = 0;
-      for (int i = 0; i < nu; ++i) un += u[i] * u[i];
       const double c_new = 0.5 * m.c * un;                                      // problem_t::l (no constraints on this path)
       dsum += c_new - cold[t];
-      rbd::eval_f_lds<NJ, NC>(m, x, u, xn, aba_state, a);                       // :50
-      for (int i = 0; i < nx; ++i) { x[i] = xn[i]; xw[(t + 1) * nx + i] = xn[i]; }
     }
+    __syncthreads();
+    rbd::aba_tree_coop<NJ, NC, NH>(m, x, x + NJ, u, qdd, aba_state, a, h, live);   // :50 (ends with a barrier)
+    if (live)
+      for (int i = h; i < NJ; i += NH) {                                        // dynamics_t::eval_to, problem.hpp:441-461
+        const double vo = m.dt * x[NJ + i];
+        const double qn = x[i] + vo;
+        const double vn = x[NJ + i] + qdd[i] * m.dt;
+        x[i] = qn; x[NJ + i] = vn;
+        xw[(t + 1) * nx + i] = qn; xw[(t + 1) * nx + NJ + i] = vn;
+      }
     __syncthreads();
   }
   if (h == 0 && live) {
@@ -392,9 +406,9 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
     prof_begin(ctx, DDP_HIP_K_FWD_ROLLOUT);
     // tree models without constraints: the latency path (one workgroup per instance, 8 lanes per candidate)
     const bool lat_path = ctx->model_h.kind == DDP_HIP_MODEL_TREE && d.Etot == 0 && n_alpha <= 8 && d.nv == 38 &&
-                          getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
+                          ctx->model_h.max_level_width <= 8 && getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
     if (lat_path) {
-      const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * 76);
+      const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));
       static bool attr = false;
       if (!attr) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -30,6 +30,12 @@ struct DevModel {
   int32_t slot_up[DDP_MAXJ];        // slot of the joint's accumulator in the leaf->root pass (-1: leaf)
   int32_t slot_down[DDP_MAXJ];      // slot of the joint's value in the root->leaf pass (-1: leaf)
   int32_t n_slots;
+  // level schedule for the wave-cooperative traversals (rbd.h: aba_tree_coop): joints sorted by tree depth
+  int32_t n_levels, max_level_width;
+  int32_t lvl_start[DDP_MAXJ + 1];  // joints of level L are lvl_joint[lvl_start[L] .. lvl_start[L+1])
+  int32_t lvl_joint[DDP_MAXJ];
+  int32_t child_start[DDP_MAXJ + 1]; // children of joint i (descending index) are child_list[child_start[i] .. child_start[i+1])
+  int32_t child_list[DDP_MAXJ];
   // constraint chain
   int32_t eq_kind, eq_advance, frame_joint, first_order_fd, fd_mode, pad_;
   double frame_off[3];

@@ -673,3 +673,144 @@ __device__ void eval_f_ucached(const DevModel& m, const double* __restrict__ qc,
 }
 
 }  // namespace rbd
+
+// ---- wave-cooperative variant: the lanes of one evaluation walk the tree level by level -----------------------------
+// NH lanes share one evaluation; in every round lane h takes the h-th joint of the current tree level (the branches of a
+// humanoid advance side by side: 16 rounds per pass instead of 38 joints).  State as in aba_tree_lds ([slot][candidate]
+// in LDS).  A child leaves its contribution to the parent (X^T Ia X, X^T pa) in its own slots; the parent adds its
+// children's contributions in descending index order, i.e. in exactly the order of the sequential loop.
+// Must be called by all lanes of the workgroup (it contains workgroup barriers); q, v, tau, qdd live in LDS.
+namespace rbd {
+
+template <int NJ, int TPB, int NH>
+__device__ void aba_tree_coop(const DevModel& m, const double* q, const double* v, const double* tau, double* qdd,
+                              double* st, int cand, int h, bool live) {
+  auto S = [&](int joint, int slot) -> double& { return st[(joint * ABA_LDS_SLOTS + slot) * TPB + cand]; };
+  constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oI = 24, oU = 45, oD = 51, oT = 52, oV = 53;
+  const int NL = m.n_levels;
+  for (int L = 0; L < NL; ++L) {                 // pass 1, root -> leaves
+    const int idx = m.lvl_start[L] + h;
+    if (live && idx < m.lvl_start[L + 1]) {
+      const int i = m.lvl_joint[idx];
+      double E[9], R[3], vel[6], vp[6], cb[6], pA[6], Iv[6], I6[21];
+      joint_placement(m, i, q[i], E, R);
+      const double* a = m.axis[i];
+      double vJ[6] = {0, 0, 0, 0, 0, 0};
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+      const int par = m.parent[i];
+      if (par >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vp[k] = S(par, oV + k);
+        xform_motion(E, R, vp, vel);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+      crm(vel, vJ, cb);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) I6[k] = m.I6[i][k];
+      sym6_mv(I6, vel, Iv);
+      crf(vel, Iv, pA);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S(i, oE + k) = E[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) S(i, oR + k) = R[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { S(i, oV + k) = vel[k]; S(i, oC + k) = cb[k]; S(i, oP + k) = pA[k]; }
+#pragma unroll
+      for (int k = 0; k < 21; ++k) S(i, oI + k) = I6[k];
+    }
+    __syncthreads();
+  }
+  for (int L = NL - 1; L >= 0; --L) {            // pass 2, leaves -> root
+    const int idx = m.lvl_start[L] + h;
+    if (live && idx < m.lvl_start[L + 1]) {
+      const int i = m.lvl_joint[idx];
+      const double* a = m.axis[i];
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      double IA[21], U[6], pAi[6], cb[6];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) IA[k] = S(i, oI + k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { pAi[k] = S(i, oP + k); cb[k] = S(i, oC + k); }
+      for (int ci = m.child_start[i]; ci < m.child_start[i + 1]; ++ci) {   // contributions, descending child index
+        const int c = m.child_list[ci];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) IA[k] += S(c, oI + k);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pAi[k] += S(c, oP + k);
+      }
+      double d = 0, sp = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) U[r] = IA[sidx(r, o)] * a[0] + IA[sidx(r, o + 1)] * a[1] + IA[sidx(r, o + 2)] * a[2];
+      for (int k = 0; k < 3; ++k) { d += a[k] * U[o + k]; sp += a[k] * pAi[o + k]; }
+      const double dinv = 1.0 / d;
+      const double ui = tau[i] - sp;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S(i, oU + k) = U[k];
+      S(i, oD) = dinv;
+      S(i, oT) = ui;
+      if (m.parent[i] >= 0) {
+        double E[9], R[3], Ia[21], pa[6], Iac[6], fp[6], Z[21];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[sidx(r, c)] - U[r] * U[c] * dinv;
+        sym6_mv(Ia, cb, Iac);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) Z[k] = 0.0;
+        add_xtix(E, R, Ia, Z);                    // this joint's contribution to its parent, left in its own slots
+#pragma unroll
+        for (int k = 0; k < 21; ++k) S(i, oI + k) = Z[k];
+        xform_force_T(E, R, pa, fp);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S(i, oP + k) = fp[k];
+      }
+    }
+    __syncthreads();
+  }
+  for (int L = 0; L < NL; ++L) {                 // pass 3, root -> leaves
+    const int idx = m.lvl_start[L] + h;
+    if (live && idx < m.lvl_start[L + 1]) {
+      const int i = m.lvl_joint[idx];
+      double E[9], R[3], ap[6], accp[6], U[6], cb[6];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { U[k] = S(i, oU + k); cb[k] = S(i, oC + k); }
+      const int par = m.parent[i];
+      if (par >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) accp[k] = S(par, oV + k);
+        xform_motion(E, R, accp, ap);
+      } else {
+        const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+        xform_motion(E, R, a0, ap);
+      }
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; s += U[k] * ap[k]; }
+      const double qd = (S(i, oT) - s) * S(i, oD);
+      qdd[i] = qd;
+      const double* a = m.axis[i];
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      ap[o] += a[0] * qd; ap[o + 1] += a[1] * qd; ap[o + 2] += a[2] * qd;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S(i, oV + k) = ap[k];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace rbd
