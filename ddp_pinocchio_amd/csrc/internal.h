@@ -102,6 +102,7 @@ struct ddp_hip_ctx {
   int32_t n_alpha_max = 8;
 
   // linearize workspace
+  double* eq_ws = nullptr;     // constraint-chain workspace (large models)
   double* lin_ws = nullptr;
   size_t lin_ws_bytes = 0;
 

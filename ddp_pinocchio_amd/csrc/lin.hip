@@ -29,6 +29,7 @@ struct LinParams {
   double *f_val, *fx, *fu, *fxx, *fux, *fuu;
   double *eq_val, *eq_x, *eq_u, *eq_xx, *eq_ux, *eq_uu;
   int32_t has_tensors;
+  double *eq_xk, *eq_fxk, *eq_c;   // large-model constraint chain workspace: x_1..x_K | f_x(x_1..x_{K-1}) | base jacobian
   double* vcache;   // [batch*T][2nv+1][nv*VC_STRIDE]: (q, v)-dependent part at (q,v), (q, v+eps e_i), (q+eps e_i, v)
   double* qcache;   // [batch*T][nv+1][nv*QC_STRIDE]: q-dependent part of the ABA at the base q and at q + eps e_i (mode 2)
 };
@@ -421,6 +422,111 @@ __device__ void eq_first_order(const DevModel& m, const double* target, int e, c
   for (int i = 0; i < e * n; ++i) out_x[i] = ex[i];
 }
 
+// ---- constraint chain, large models: the same chain rule as eq_first_order, as three kernels ---------------------
+// (the per-lane variant above would need n x n private matrices per lane)
+template <int NJ>
+__global__ void eq_chain_kernel(LinParams p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t T = p.d.T;
+  if (gid >= p.d.batch * T) return;
+  const int b = (int)(gid / T);
+  const int64_t t = gid % T;
+  const int e = (int)p.ne[t];
+  if (e == 0) return;
+  const DevModel& m = *p.model;
+  const int nv = m.nv, n = 2 * nv, K = m.eq_advance;
+  const int64_t Eo = p.Epre[t], Eb = (int64_t)b * p.d.Etot + Eo;
+  double xa[2 * NJ], xb[2 * NJ], u[NJ];
+  load_xu<NJ>(p, b, t, xa, u);
+  for (int k = 0; k < K; ++k) {                          // x_{k+1} = f(x_k, u): the SAME u at every look-ahead step
+    rbd::eval_f<NJ>(m, xa, u, xb);
+    for (int i = 0; i < n; ++i) { xa[i] = xb[i]; p.eq_xk[(gid * K + k) * n + i] = xb[i]; }
+  }
+  double* C = p.eq_c + gid * (int64_t)p.d.emax * n;
+  for (int i = 0; i < e * n; ++i) C[i] = 0.0;
+  const double* target = p.target + Eo;
+  if (m.eq_kind == DDP_HIP_EQ_CONFIG) {
+    for (int i = 0; i < e; ++i) { p.eq_val[Eb + i] = xa[i] - target[i]; C[i + i * e] = 1.0; }   // d_difference_dq_finish = I
+  } else {
+    double pos[3], J[3 * NJ];
+    rbd::frame_position<NJ>(m, xa, pos, J);
+    for (int i = 0; i < e; ++i) p.eq_val[Eb + i] = pos[i] - target[i];
+    for (int j = 0; j < nv; ++j)
+      for (int i = 0; i < e; ++i) C[i + j * e] = J[i + 3 * j];
+  }
+}
+
+// forward-difference f_x at the look-ahead states x_1 .. x_{K-1}: one lane per (b, t, k, column)
+template <int NJ>
+__global__ void eq_fdjac_kernel(LinParams p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t T = p.d.T;
+  const DevModel& m = *p.model;
+  const int n = 2 * m.nv, K = m.eq_advance;
+  if (K < 2 || gid >= p.d.batch * T * (K - 1) * n) return;
+  const int j = (int)(gid % n);
+  const int k = (int)((gid / n) % (K - 1));               // Jacobian at x_{k+1}
+  const int64_t bt = gid / ((int64_t)n * (K - 1));
+  const int b = (int)(bt / T);
+  const int64_t t = bt % T;
+  if (p.ne[t] == 0) return;
+  double x[2 * NJ], u[NJ], f[2 * NJ];
+  const double* xk = p.eq_xk + (bt * K + k) * n;           // x_{k+1}
+  const double* xk1 = p.eq_xk + (bt * K + k + 1) * n;      // x_{k+2} = f(x_{k+1}, u)
+  const double* us = p.u + ((int64_t)b * T + t) * m.nv;
+  for (int i = 0; i < n; ++i) x[i] = xk[i];
+  for (int i = 0; i < m.nv; ++i) u[i] = us[i];
+  const double eps = sqrt(DBL_EPSILON);
+  x[j] = x[j] + eps;
+  rbd::eval_f<NJ>(m, x, u, f);
+  double* col = p.eq_fxk + (bt * (K - 1) + k) * (int64_t)n * n + (int64_t)j * n;
+  for (int i = 0; i < n; ++i) col[i] = (f[i] - xk1[i]) / eps;
+}
+
+// eq_x = C f_x(x_{K-1}) ... f_x(x_1) f_x(x_0),  eq_u = C f_x(x_{K-1}) ... f_x(x_1) f_u(x_0)   (problem.hpp:603-604)
+__global__ void eq_combine_kernel(LinParams p) {
+  const int64_t bt = blockIdx.x;
+  const int64_t T = p.d.T;
+  const int b = (int)(bt / T);
+  const int64_t t = bt % T;
+  const int e = (int)p.ne[t];
+  if (e == 0) return;
+  const int n = (int)p.d.n, mm = (int)p.d.m, K = p.model->eq_advance;
+  const int64_t Eb = (int64_t)b * p.d.Etot + p.Epre[t];
+  extern __shared__ double sm[];
+  double* ex = sm;
+  double* tmp = sm + (int64_t)p.d.emax * n;
+  const double* C = p.eq_c + bt * (int64_t)p.d.emax * n;
+  for (int i = threadIdx.x; i < e * n; i += blockDim.x) ex[i] = C[i];
+  __syncthreads();
+  for (int k = K - 2; k >= 0; --k) {
+    const double* F = p.eq_fxk + (bt * (K - 1) + k) * (int64_t)n * n;
+    for (int idx = threadIdx.x; idx < e * n; idx += blockDim.x) {
+      const int i = idx % e, j = idx / e;
+      double s = 0;
+      for (int l = 0; l < n; ++l) s += ex[i + l * e] * F[l + (int64_t)j * n];
+      tmp[idx] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < e * n; i += blockDim.x) ex[i] = tmp[i];
+    __syncthreads();
+  }
+  const double* fx = p.fx + bt * n * n;
+  const double* fu = p.fu + bt * n * mm;
+  for (int idx = threadIdx.x; idx < e * n; idx += blockDim.x) {
+    const int i = idx % e, j = idx / e;
+    double s = 0;
+    for (int l = 0; l < n; ++l) s += ex[i + l * e] * fx[l + j * n];
+    p.eq_x[Eb * n + idx] = s;
+  }
+  for (int idx = threadIdx.x; idx < e * mm; idx += blockDim.x) {
+    const int i = idx % e, j = idx / e;
+    double s = 0;
+    for (int l = 0; l < n; ++l) s += ex[i + l * e] * fu[l + j * n];
+    p.eq_u[Eb * mm + idx] = s;
+  }
+}
+
 #define MAXADV 4
 
 template <int NJ>
@@ -586,6 +692,13 @@ LinParams make_params(ddp_hip_ctx* ctx) {
   p.eq_val = S(DDP_HIP_SEQ_EQ_VAL); p.eq_x = S(DDP_HIP_SEQ_EQ_X); p.eq_u = S(DDP_HIP_SEQ_EQ_U);
   p.eq_xx = S(DDP_HIP_SEQ_EQ_XX); p.eq_ux = S(DDP_HIP_SEQ_EQ_UX); p.eq_uu = S(DDP_HIP_SEQ_EQ_UU);
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
+  p.eq_xk = ctx->eq_ws;
+  if (p.eq_xk) {
+    const Dims& dd = ctx->d;
+    const int64_t K = ctx->model_h.eq_advance;
+    p.eq_fxk = p.eq_xk + dd.batch * dd.T * K * dd.nx;
+    p.eq_c = p.eq_fxk + dd.batch * dd.T * (K > 1 ? K - 1 : 0) * dd.n * dd.n;
+  }
   p.qcache = reinterpret_cast<double*>(ctx->lin_ws);
   p.vcache = p.qcache ? p.qcache + ctx->d.batch * ctx->d.T * (ctx->d.nv + 1) * ctx->d.nv * rbd::QC_STRIDE : nullptr;
   return p;
@@ -653,7 +766,27 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
           HIP_TRY(hipMemsetAsync(p.eq_uu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UU].size * d.batch), ctx->stream));
         }
       }
-    } else return DDP_HIP_E_UNSUPPORTED;   // constraint chains on large models: next round
+    } else {
+      // large models: chain rule as three kernels; mode-2 second order reuses the per-point kernel
+      if (!p.eq_xk) return DDP_HIP_E_UNSUPPORTED;
+      const int K = ctx->model_h.eq_advance;
+      if (K < 1) return DDP_HIP_E_UNSUPPORTED;
+      hipLaunchKernelGGL((eq_chain_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
+      if (K > 1) hipLaunchKernelGGL((eq_fdjac_kernel<NJ>), dim3(blocks_for(BT * (K - 1) * d.n)), dim3(LBS), 0, ctx->stream, p);
+      hipLaunchKernelGGL(eq_combine_kernel, dim3((unsigned)BT), dim3(256), sizeof(double) * (size_t)(2 * d.emax * d.n), ctx->stream, p);
+      if (p.has_tensors) {
+        if (fd_mode == 2) {
+          hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
+          hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p, 1);
+        } else if (fd_mode == 1) {
+          return DDP_HIP_E_UNSUPPORTED;
+        } else {
+          HIP_TRY(hipMemsetAsync(p.eq_xx, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_XX].size * d.batch), ctx->stream));
+          HIP_TRY(hipMemsetAsync(p.eq_ux, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UX].size * d.batch), ctx->stream));
+          HIP_TRY(hipMemsetAsync(p.eq_uu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UU].size * d.batch), ctx->stream));
+        }
+      }
+    }
   }
   HIP_TRY(hipGetLastError());
   return DDP_HIP_OK;
@@ -670,9 +803,17 @@ int lin_setup(ddp_hip_ctx* ctx) {
     ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * ((d.nv + 1) * d.nv * rbd::QC_STRIDE + (2 * d.nv + 1) * d.nv * rbd::VC_STRIDE));
     HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));
   }
+  // look-ahead states / jacobians of the constraint chain on large models
+  if (ctx->d.Etot > 0 && ctx->d.nv > 6) {
+    const Dims& d = ctx->d;
+    const int64_t K = ctx->model_h.eq_advance;
+    const size_t words = (size_t)(d.batch * d.T * (K * d.nx + (K > 1 ? K - 1 : 0) * d.n * d.n + d.emax * d.n));
+    HIP_TRY(hipMalloc(&ctx->eq_ws, sizeof(double) * words));
+  }
   return DDP_HIP_OK;
 }
 void lin_teardown(ddp_hip_ctx* ctx) {
+  if (ctx->eq_ws) (void)hipFree(ctx->eq_ws);
   if (ctx->lin_ws) (void)hipFree(ctx->lin_ws);
 }
 

@@ -20,6 +20,15 @@ def make(name, T, batch=1, fd_mode=2, seed=1):
         ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 3
         kw = dict(eq_kind=capi.EQ_FRAME, eq_advance=2, ne=ne, eq_target=np.array([0.3, 0.2, 0.4]), frame_joint=5,
                   frame_off=(0.0, 0.0, 0.0823))
+    elif name == "tree38_frame":  # BASELINE config 5 shape: Talos-like tree + 3-row frame translation at t = T-2
+        model = capi.BuiltinModel(capi.BUILTIN_TREE38, seed)
+        ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 3
+        kw = dict(eq_kind=capi.EQ_FRAME, eq_advance=2, ne=ne, eq_target=np.array([0.4, -0.1, 0.9]), frame_joint=27,
+                  frame_off=(0.0, 0.0, 0.1))
+    elif name == "tree38_config":  # config constraint on every joint at every step (pinocchio_ddp.cpp shape, Talos size)
+        model = capi.BuiltinModel(capi.BUILTIN_TREE38, seed)
+        ne = np.full(T, 38, dtype=np.int64)
+        kw = dict(eq_kind=capi.EQ_CONFIG, eq_advance=2, ne=ne, eq_target=np.zeros(38 * T))
     elif name == "tree38":        # Talos-like, unconstrained
         model = capi.BuiltinModel(capi.BUILTIN_TREE38, seed)
         kw = dict(eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))

@@ -79,6 +79,7 @@ def _abs_err(ctx, d, key, seq):
 @pytest.mark.parametrize("name,T,fd_mode", [
     ("pendulum", 50, 2), ("pendulum", 50, 1), ("pendulum", 9, 0),
     ("chain6", 10, 2), ("chain6_frame", 10, 2), ("tree38", 4, 2), ("tree38", 5, 0),
+    ("tree38_frame", 4, 2), ("tree38_frame", 5, 0), ("tree38_config", 3, 2),
 ])
 def test_linearize_parity(gpu, name, T, fd_mode):
     capi = gpu
@@ -131,7 +132,8 @@ def test_linearize_parity(gpu, name, T, fd_mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,T", [("pendulum", 50), ("chain6", 10), ("chain6_frame", 12), ("tree38", 12)])
+@pytest.mark.parametrize("name,T", [("pendulum", 50), ("chain6", 10), ("chain6_frame", 12), ("tree38", 12),
+                                    ("tree38_frame", 12), ("tree38_config", 6)])
 def test_cost_seq_aug_parity(gpu, name, T):
     capi = gpu
     model, spec, o = make(name, T)
@@ -173,6 +175,8 @@ def _one_iteration_inputs(o, model, seed, mu, u_sigma, jac_sigma):
     ("chain6", 10, 2, 100.0, 0.05, 0.01, 40.0),     # overshooting feed-forward: the line search has to halve
     ("tree38", 10, 0, 1.0, 0.3, 0.0, 1.0),
     ("tree38", 10, 0, 1.0, 0.3, 0.0, 30.0),
+    ("tree38_frame", 10, 0, 100.0, 0.3, 0.01, 1.0),
+    ("tree38_frame", 10, 0, 100.0, 0.3, 0.01, 30.0),
 ])
 def test_forward_parity(gpu, name, T, fd_mode, mu, u_sigma, jac_sigma, k_scale):
     """Same accepted step as the reference's sequential halving, same new trajectory (ddp_fwd.ipp:9-67)."""
