@@ -105,6 +105,7 @@ struct ddp_hip_ctx {
   double* eq_ws = nullptr;     // constraint-chain workspace (large models)
   double* lin_ws = nullptr;
   size_t lin_ws_bytes = 0;
+  bool lin_static = false;     // the model's tree matches a compiled-in topology (lin_static.hip)
 
   bool profile = false;
   ProfSlot prof[DDP_HIP_K_COUNT];

@@ -14,27 +14,12 @@
 #include <stdlib.h>
 
 #include "internal.h"
+#include "lin_common.h"
 #include "rbd.h"
 
 namespace {
 
-struct LinParams {
-  Dims d;
-  const DevModel* model;
-  const int64_t* ne;
-  const int64_t* Epre;
-  const double* target;
-  const double *x, *u;
-  double *lfx, *lfxx, *lx, *lu, *lxx, *lux, *luu;
-  double *f_val, *fx, *fu, *fxx, *fux, *fuu;
-  double *eq_val, *eq_x, *eq_u, *eq_xx, *eq_ux, *eq_uu;
-  int32_t has_tensors;
-  double *eq_xk, *eq_fxk, *eq_c;   // large-model constraint chain workspace: x_1..x_K | f_x(x_1..x_{K-1}) | base jacobian
-  double* vcache;   // [batch*T][2nv+1][nv*VC_STRIDE]: (q, v)-dependent part at (q,v), (q, v+eps e_i), (q+eps e_i, v)
-  double* qcache;   // [batch*T][nv+1][nv*QC_STRIDE]: q-dependent part of the ABA at the base q and at q + eps e_i (mode 2)
-};
 
-constexpr int LBS = 64;
 
 // cost derivatives, problem.hpp:958-959,982-987:  lx = 0, lxx = 0, lux = 0, lu = c u^T, luu = c I
 __global__ void lin_cost_kernel(LinParams p) {
@@ -733,7 +718,8 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
-        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 3>), dim3(blocks_for(BT * Pu)), dim3(LBS), 0, ctx->stream, p);
+        if (ctx->lin_static) lin_static_launch(ctx, p, 3);
+        else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 3>), dim3(blocks_for(BT * Pu)), dim3(LBS), 0, ctx->stream, p);
       } else {
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 0>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p);
@@ -803,6 +789,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
     ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * ((d.nv + 1) * d.nv * rbd::QC_STRIDE + (2 * d.nv + 1) * d.nv * rbd::VC_STRIDE));
     HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));
   }
+  ctx->lin_static = want && lin_static_supported(ctx->model_h) && getenv("DDP_HIP_NO_STATIC") == nullptr;
   // look-ahead states / jacobians of the constraint chain on large models
   if (ctx->d.Etot > 0 && ctx->d.nv > 6) {
     const Dims& d = ctx->d;

@@ -1,0 +1,26 @@
+// lin_common.h -- parameter block shared by the linearisation translation units (lin.hip, lin_static.hip)
+#pragma once
+#include "internal.h"
+
+struct LinParams {
+  Dims d;
+  const DevModel* model;
+  const int64_t* ne;
+  const int64_t* Epre;
+  const double* target;
+  const double *x, *u;
+  double *lfx, *lfxx, *lx, *lu, *lxx, *lux, *luu;
+  double *f_val, *fx, *fu, *fxx, *fux, *fuu;
+  double *eq_val, *eq_x, *eq_u, *eq_xx, *eq_ux, *eq_uu;
+  int32_t has_tensors;
+  double *eq_xk, *eq_fxk, *eq_c;   // large-model constraint chain workspace: x_1..x_K | f_x(x_1..x_{K-1}) | base jacobian
+  double* vcache;   // [batch*T][2nv+1][nv*VC_STRIDE]: (q, v)-dependent part at (q,v), (q, v+eps e_i), (q+eps e_i, v)
+  double* qcache;   // [batch*T][nv+1][nv*QC_STRIDE]: q-dependent part of the ABA at the base q and at q + eps e_i (mode 2)
+};
+
+constexpr int LBS = 64;
+
+// static-topology second-order path (lin_static.hip): returns true when the model's tree matches a compiled-in
+// topology; the launcher covers the velocity- and torque-level stencil points of finite_diff_hessian_compute mode 2
+bool lin_static_supported(const DevModel& m);
+void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level);

@@ -1,0 +1,435 @@
+// lin_static.hip -- second-order finite differences (finite_diff_hessian_compute mode 2, problem.hpp:152-298) for
+// trees whose TOPOLOGY is known at compile time.
+//
+// The generic kernels of lin.hip keep the per-joint state of an evaluation in private arrays indexed by run-time
+// joint / slot numbers; those arrays live in scratch (HBM-backed) and their traffic is what bounds the stencil
+// (profiles/: 39 KB written per evaluation at the Talos size).  Here the parent table is a template parameter: every
+// loop over the joints is expanded at compile time, every index is a constant and the running state of an
+// evaluation lives in registers.  One wave = 64 stencil points that share their configuration q (and, at the
+// torque level, their velocity): what the articulated-body algorithm derives from q (and v) alone is read from the
+// q- / v-caches through the scalar path (wave-uniform addresses), each lane only carries what its own perturbation
+// changes.  The arithmetic is the operation sequence of rbd::aba_u_cached / rbd::aba_vu_cached.
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+
+#include <utility>
+
+#include "internal.h"
+#include "lin_common.h"
+#include "rbd.h"
+
+namespace {
+
+// ---- compiled-in topologies -------------------------------------------------------------------------------------
+// Talos-like humanoid (models.cpp:build_tree38): floating base as 3 prismatic + 3 revolute joints, two 6-joint legs,
+// a 2-joint torso, two 8-joint arms, a 2-joint head
+struct TopoTalos38 {
+  static constexpr int N = 38;
+  static constexpr int parent[N] = {-1, 0, 1, 2, 3, 4,            // base
+                                    5, 6, 7, 8, 9, 10,            // left leg
+                                    5, 12, 13, 14, 15, 16,        // right leg
+                                    5, 18,                        // torso
+                                    19, 20, 21, 22, 23, 24, 25, 26,   // left arm
+                                    19, 28, 29, 30, 31, 32, 33, 34,   // right arm
+                                    19, 36};                      // head
+  static constexpr int prismatic[N] = {1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                       0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+template <class T> constexpr bool has_child(int k) {
+  for (int c = k + 1; c < T::N; ++c) if (T::parent[c] == k) return true;
+  return false;
+}
+template <class T> constexpr int largest_child(int k) {
+  int r = -1;
+  for (int c = k + 1; c < T::N; ++c) if (T::parent[c] == k) r = c;
+  return r;
+}
+// the largest-index child of its parent contributes first in the leaf -> root pass
+template <class T> constexpr bool first_contrib(int k) { return T::parent[k] >= 0 && largest_child<T>(T::parent[k]) == k; }
+
+template <class T>
+bool topo_matches(const DevModel& m) {
+  if (m.kind != DDP_HIP_MODEL_TREE || m.nv != T::N) return false;
+  for (int i = 0; i < T::N; ++i)
+    if (m.parent[i] != T::parent[i] || (m.jtype[i] == DDP_HIP_JOINT_PRISMATIC) != (T::prismatic[i] != 0)) return false;
+  return true;
+}
+
+// ---- per-lane state ----------------------------------------------------------------------------------------------
+template <class T>
+struct TauState {
+  double acc[T::N][6];   // leaf -> root: bias-force accumulators of the joints that have children; root -> leaf: accelerations
+  double uu[T::N];       // u_i = tau_i - S_i^T pA_i, then the joint acceleration
+};
+
+// leaf -> root step of joint K for a new tau (rbd::aba_u_cached, first loop)
+template <class T, int K>
+__device__ __forceinline__ void tau_up(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc,
+                                       double tauK, TauState<T>& s) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* E = qc + K * rbd::QC_STRIDE;
+  const double* r = E + 9;
+  const double* U = E + 12;
+  const double dinv = E[18];
+  const double* pA0 = vc + K * rbd::VC_STRIDE + 6;
+  const double* Iac = vc + K * rbd::VC_STRIDE + 12;
+  const double* a = m.axis[K];
+  double pAi[6];
+  if constexpr (has_child<T>(K)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pAi[k] = s.acc[K][k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pAi[k] = pA0[k];
+  }
+  double sp = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sp += a[k] * pAi[o + k];
+  const double ui = tauK - sp;
+  s.uu[K] = ui;
+  constexpr int par = T::parent[K];
+  if constexpr (par >= 0) {
+    double pa[6], fp[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
+    rbd::xform_force_T(E, r, pa, fp);
+    if constexpr (first_contrib<T>(K)) {
+      const double* pp0 = vc + par * rbd::VC_STRIDE + 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s.acc[par][k] = pp0[k] + fp[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s.acc[par][k] += fp[k];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep the operand loads of the next joint out of this one: SGPRs would spill
+}
+
+// root -> leaf step of joint K (rbd::aba_u_cached, second loop); leaves the joint acceleration in uu[K]
+template <class T, int K>
+__device__ __forceinline__ void tau_down(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc,
+                                         TauState<T>& s) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* E = qc + K * rbd::QC_STRIDE;
+  const double* r = E + 9;
+  const double* U = E + 12;
+  const double dinv = E[18];
+  const double* cb = vc + K * rbd::VC_STRIDE;
+  double ap[6];
+  constexpr int par = T::parent[K];
+  if constexpr (par >= 0) rbd::xform_motion(E, r, s.acc[par], ap);
+  else {
+    const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    rbd::xform_motion(E, r, a0, ap);
+  }
+  double sum = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; sum += U[k] * ap[k]; }
+  const double qd = (s.uu[K] - sum) * dinv;
+  s.uu[K] = qd;
+  if constexpr (has_child<T>(K)) {
+    const double* a = m.axis[K];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s.acc[K][k] = ap[k];
+    s.acc[K][o] += a[0] * qd; s.acc[K][o + 1] += a[1] * qd; s.acc[K][o + 2] += a[2] * qd;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <class T, class TauFn, int... Ks>
+__device__ __forceinline__ void tau_up_all(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc, TauFn tau,
+                                           TauState<T>& s, std::integer_sequence<int, Ks...>) {
+  (tau_up<T, T::N - 1 - Ks>(m, qc, vc, tau(T::N - 1 - Ks), s), ...);
+}
+template <class T, int... Ks>
+__device__ __forceinline__ void tau_down_all(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc,
+                                             TauState<T>& s, std::integer_sequence<int, Ks...>) {
+  (tau_down<T, Ks>(m, qc, vc, s), ...);
+}
+
+// Pull a wave-uniform block into the L2 ahead of the scalar loads that walk it: 64 lanes x 16 bytes per KiB, all in
+// flight at once (the scalar path alone would pay the HBM latency once per 64-byte line, one line after the other).
+// Returns a word that depends on every byte loaded; the caller folds it into the start of its dependency chain so that
+// the evaluation begins once the block has arrived.  Plain loads on purpose: inline asm or a memory-writing intrinsic
+// anywhere ahead of the operand loads makes the compiler fall back from scalar to per-lane vector loads.
+template <int BYTES>
+__device__ __forceinline__ unsigned int warm_block(const double* base, int lane) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const char* b = reinterpret_cast<const char*>(base);
+  unsigned int sink = 0;
+#pragma unroll
+  for (int off = 0; off < BYTES; off += LBS * 16) {
+    int o = off + lane * 16;
+    o = o < BYTES - 16 ? o : BYTES - 16;
+    const u4 v = *reinterpret_cast<const u4*>(b + o);
+    sink ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  return sink;
+}
+
+__device__ __forceinline__ void tri_index(int64_t q, int Wd, int& ii, int& jj) {   // q -> (ii, jj), ii < jj < Wd, row by row
+  int a = (int)floor(((2.0 * Wd - 1.0) - sqrt((2.0 * Wd - 1.0) * (2.0 * Wd - 1.0) - 8.0 * (double)q)) * 0.5);
+  if (a < 0) a = 0;
+  while ((int64_t)a * (2 * Wd - a - 1) / 2 > q) --a;
+  while ((int64_t)(a + 1) * (2 * Wd - a - 2) / 2 <= q) ++a;
+  ii = a;
+  jj = (int)(q - (int64_t)a * (2 * Wd - a - 1) / 2) + a + 1;
+}
+
+// ---- output stage (problem.hpp:226-296) ---------------------------------------------------------------------------
+// Each stencil point owns one n-double column of a tensor (two for a symmetric pair) and reads four more columns
+// (its two first-order columns and its two diagonal second-order columns).  Every lane leaves the accelerations of
+// its evaluation and the six column addresses of its point in LDS; the wave then walks the points four at a time
+// with 16 lanes on each column (128-byte runs), NB such groups in flight so that their loads overlap.
+template <int NV>
+struct OutStage {
+  double qdd[NV][LBS];          // [joint][lane]
+  const double* in[4][LBS];     // fcol_1, fcol_2, diagonal column 1, diagonal column 2
+  double* out[2][LBS];          // the point's column and its mirror image (or null)
+  int pi[LBS];                  // first perturbed direction (rows of f that see it directly)
+};
+
+template <int NV, bool UNIFORM_I>
+__device__ __forceinline__ void offdiag_output(const LinParams& p, OutStage<NV>& S, bool valid, int i, int j, int64_t bt,
+                                               const double* __restrict__ xg, double dt) {
+  constexpr int n = 2 * NV, mm = NV;
+  constexpr int CH = 16, EPI = LBS / CH, NB = 4;
+  const double eps = sqrt(sqrt(DBL_EPSILON));
+  const double eps2 = eps * eps;
+  const int lane = threadIdx.x;
+  {
+    double* fxx = p.fxx + bt * n * n * n;
+    double* fux = p.fux + bt * n * mm * n;
+    double* fuu = p.fuu + bt * n * mm * mm;
+    const double* fxb = p.fx + bt * n * n;
+    const double* fub = p.fu + bt * n * mm;
+    const bool at_x_1 = i < n, at_x_2 = j < n;
+    const int idx_1 = at_x_1 ? i : i - n, idx_2 = at_x_2 ? j : j - n;
+    S.in[0][lane] = at_x_1 ? fxb + (int64_t)idx_1 * n : fub + (int64_t)idx_1 * n;
+    S.in[1][lane] = at_x_2 ? fxb + (int64_t)idx_2 * n : fub + (int64_t)idx_2 * n;
+    S.in[2][lane] = at_x_1 ? fxx + (int64_t)idx_1 * n + (int64_t)idx_1 * n * n : fuu + (int64_t)idx_1 * n + (int64_t)idx_1 * n * mm;
+    S.in[3][lane] = at_x_2 ? fxx + (int64_t)idx_2 * n + (int64_t)idx_2 * n * n : fuu + (int64_t)idx_2 * n + (int64_t)idx_2 * n * mm;
+    double* tensor;
+    int L;
+    if (at_x_1) { if (at_x_2) { tensor = fxx; L = n; } else { tensor = fux; L = mm; } }
+    else { tensor = fuu; L = mm; }
+    S.out[0][lane] = valid ? tensor + (int64_t)idx_2 * n + (int64_t)idx_1 * n * L : nullptr;
+    S.out[1][lane] = (valid && at_x_1 == at_x_2) ? tensor + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L : nullptr;
+    S.pi[lane] = i;
+  }
+  __syncthreads();
+  const int kk = lane % CH, esub = lane / CH;
+  const double* f0 = p.f_val + bt * n;
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const int k = c0 + kk;
+    if (k >= n) continue;
+    const double f0k = f0[k];
+    const double xk = xg[k];
+    const double xvk = k < NV ? xg[NV + k] : 0.0;
+    double a1k = 0, d1k = 0;
+    if (UNIFORM_I) { a1k = S.in[0][0][k]; d1k = S.in[2][0][k]; }    // the first direction is the same for the whole wave
+    for (int r0 = 0; r0 < LBS / EPI; r0 += NB) {
+      double a1[NB], a2[NB], d1[NB], d2[NB], fv[NB];
+      double* o0[NB];
+      double* o1[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int e = (r0 + u) * EPI + esub;
+        o0[u] = S.out[0][e];
+        o1[u] = S.out[1][e];
+        const int ie = S.pi[e];
+        // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461); the second direction is a v or u one
+        const double xs = k == ie ? xk + eps : xk;
+        if (k < NV) {
+          const double xv = (NV + k) == ie ? xvk + eps : xvk;
+          const double vo = dt * xv;
+          fv[u] = xs + vo;
+        } else {
+          fv[u] = xs + S.qdd[k - NV][e] * dt;
+        }
+        if (o0[u]) {
+          a2[u] = S.in[1][e][k]; d2[u] = S.in[3][e][k];
+          if (UNIFORM_I) { a1[u] = a1k; d1[u] = d1k; } else { a1[u] = S.in[0][e][k]; d1[u] = S.in[2][e][k]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        if (!o0[u]) continue;
+        double df = fv[u] - f0k;                          // difference_out
+        df -= eps * a1[u];
+        df -= eps * a2[u];
+        df *= 2;
+        const double val = 0.5 * (df / eps2 - d1[u] - d2[u]);
+        o0[u][k] = val;
+        if (o1[u]) o1[u][k] = val;
+      }
+    }
+  }
+}
+
+// ---- output stage for a row of the stencil: first direction i shared by the wave, second direction jb + lane -----
+// The NV columns such a wave owns are one contiguous block of its tensor (element (k, lane) at k + lane n), and so
+// is the block of first-order columns they read: the wave walks the block linearly, 64 consecutive doubles per
+// instruction.  The per-row quantities (f, the first-order and diagonal second-order column of direction i, x) are
+// staged in LDS once; the accelerations are left in LDS lane-major with an odd row stride (conflict free both ways).
+template <int NV>
+struct RowStage {
+  double q[(NV + 1) * (NV + 1)];   // one extra row: where the idle lanes of the wave leave their values
+  double f0[2 * NV], a1[2 * NV], d1[2 * NV], x[2 * NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void rowblock_stage(RowStage<NV>& S, int lane, const double* __restrict__ f0, const double* __restrict__ a1,
+                                               const double* __restrict__ d1, const double* __restrict__ xg) {
+  constexpr int n = 2 * NV;
+  for (int k = lane; k < n; k += LBS) { S.f0[k] = f0[k]; S.a1[k] = a1[k]; S.d1[k] = d1[k]; S.x[k] = xg[k]; }
+}
+
+// out: the block [NV][n]; mirror (or null): column c at mirror + c * mstride; a2: contiguous [NV][n]; d2: column c at d2 + c * dstride
+// i: first direction (an x index); jb: x index of the second direction of column 0, or a value >= 2 NV for u directions
+template <int NV>
+__device__ __forceinline__ void rowblock_output(const RowStage<NV>& S, int lane, int i, int jb, double* __restrict__ out,
+                                                double* __restrict__ mirror, int64_t mstride, const double* __restrict__ a2,
+                                                const double* __restrict__ d2, int64_t dstride, double dt) {
+  constexpr int n = 2 * NV, TOT = NV * n, UB = 8;
+  const double eps = sqrt(sqrt(DBL_EPSILON));
+  const double eps2 = eps * eps;
+  for (int e0 = 0; e0 < TOT; e0 += UB * LBS) {
+    double va2[UB], vd2[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * LBS + lane;
+      if (e < TOT) {
+        const int c = e / n, k = e - c * n;
+        va2[u] = a2[e];
+        vd2[u] = d2[k + c * dstride];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * LBS + lane;
+      if (e >= TOT) continue;
+      const int c = e / n, k = e - c * n;
+      const int jp = jb + c;
+      // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
+      double xk = S.x[k];
+      if (k == i) xk = xk + eps;
+      if (k == jp) xk = xk + eps;
+      double fv;
+      if (k < NV) {
+        double xv = S.x[NV + k];
+        if (NV + k == i) xv = xv + eps;
+        if (NV + k == jp) xv = xv + eps;
+        const double vo = dt * xv;
+        fv = xk + vo;
+      } else {
+        fv = xk + S.q[c * (NV + 1) + (k - NV)] * dt;
+      }
+      double df = fv - S.f0[k];                          // difference_out
+      df -= eps * S.a1[k];
+      df -= eps * va2[u];
+      df *= 2;
+      const double val = 0.5 * (df / eps2 - S.d1[k] - vd2[u]);
+      out[e] = val;
+      if (mirror) mirror[k + c * mstride] = val;
+    }
+  }
+}
+
+// ---- torque level: the (x_i, u_j) and (u_i, u_j) points -------------------------------------------------------------
+// One wave per group; the groups of one (instance, t):
+//   g <  nv        : (q_g, u_lane)       cfg 1+g, vcfg nv+1+g   38 of 64 lanes
+//   g <  2 nv      : (v_{g-nv}, u_lane)  cfg 0,   vcfg 1+(g-nv) 38 of 64 lanes
+//   g >= 2 nv      : (u_i, u_j) pairs    cfg 0,   vcfg 0        64 pairs per wave
+template <class T, int MODE, bool ROWS>
+__global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
+  constexpr int nv = T::N, n = 2 * nv;
+  constexpr int TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS, G = ROWS ? 2 * nv : GU;
+  const int64_t bt = blockIdx.x / G;
+  const int g = (int)(blockIdx.x % G) + (ROWS ? 0 : 2 * nv);
+  const int lane = threadIdx.x;
+  const int64_t Tn = p.d.T;
+  const int b = (int)(bt / Tn);
+  const int64_t t = bt % Tn;
+  const DevModel& m = *p.model;
+  int i, j, cfg, vcfg;
+  bool valid;
+  if (g < nv) { i = g; j = n + lane; cfg = 1 + g; vcfg = nv + 1 + g; valid = lane < nv; }
+  else if (g < 2 * nv) { i = g; j = n + lane; cfg = 0; vcfg = 1 + (g - nv); valid = lane < nv; }
+  else {
+    const int pid = (g - 2 * nv) * LBS + lane;
+    valid = pid < TRI;
+    tri_index(valid ? pid : 0, nv, i, j);
+    i += n; j += n; cfg = 0; vcfg = 0;
+  }
+  double eps = sqrt(sqrt(DBL_EPSILON));
+  const double* __restrict__ qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
+  const double* __restrict__ vc = p.vcache + (bt * (2 * nv + 1) + vcfg) * (int64_t)nv * rbd::VC_STRIDE;
+  const double* __restrict__ xg = p.x + ((int64_t)b * (Tn + 1) + t) * n;
+  const double* __restrict__ ug = p.u + ((int64_t)b * Tn + t) * nv;
+  const int iu = i - n, ju = j - n;
+  const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(qc, lane) ^ warm_block<nv * rbd::VC_STRIDE * 8>(vc, lane);
+  if (w == 0x7fc01234u) eps = 0.0;     // never true for cache contents that are finite doubles in practice; orders the chain
+  TauState<T> s;
+  auto tau = [&](int k) { double v = ug[k]; if (k == iu) v = v + eps; if (k == ju) v = v + eps; return v; };
+  if (MODE != 1) {
+    tau_up_all<T>(m, qc, vc, tau, s, std::make_integer_sequence<int, nv>{});
+    tau_down_all<T>(m, qc, vc, s, std::make_integer_sequence<int, nv>{});
+  } else {
+    for (int k = 0; k < nv; ++k) s.uu[k] = tau(k);
+  }
+  if (MODE == 2) {
+    double acc = 0;
+    for (int k = 0; k < nv; ++k) acc += s.uu[k];
+    if (valid && acc == 1.2345) p.fuu[bt] = acc;
+    return;
+  }
+  // The output stage reads its pointers from the kernel-argument segment only now: taken from `p` they would be
+  // loaded at kernel entry and stay live through the whole evaluation, and the scalar registers would spill.
+  __builtin_amdgcn_sched_barrier(0);
+  typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
+  const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (ROWS) {
+    __shared__ RowStage<nv> S;
+    const int mm = nv;
+    // unconditional on purpose: under `if (valid)` the optimiser sinks the whole evaluation into the branch, away from
+    // its operand loads, and every operand then spills
+    const int row = valid ? lane : nv;
+#pragma unroll
+    for (int k = 0; k < nv; ++k) S.q[row * (nv + 1) + k] = s.uu[k];
+    // (the staging loop comes after these stores: the evaluation must meet its first use in its own basic block)
+    rowblock_stage<nv>(S, lane, kp->f_val + bt * n, kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg);
+    __syncthreads();
+    // column (k, u_c) of the (x_i, u) slab of f_ux: k + c n + i n m
+    rowblock_output<nv>(S, lane, i, n, kp->fux + bt * n * mm * n + (int64_t)i * n * mm, nullptr, 0, kp->fu + bt * n * mm,
+                        kp->fuu + bt * n * mm * mm, (int64_t)n + (int64_t)n * mm, m.dt);
+  } else {
+    __shared__ OutStage<nv> S;
+#pragma unroll
+    for (int k = 0; k < nv; ++k) S.qdd[k][lane] = s.uu[k];
+    LinParams po;
+    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
+    offdiag_output<nv, false>(po, S, valid, i, j, bt, xg, m.dt);
+  }
+}
+
+}  // namespace
+
+bool lin_static_supported(const DevModel& m) { return topo_matches<TopoTalos38>(m); }
+
+// level 3: torque-level points (replaces lin_offdiag_kernel<NJ, 3>)
+void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
+  using T = TopoTalos38;
+  const int64_t BT = ctx->d.batch * ctx->d.T;
+  constexpr int nv = T::N, TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS;
+  if (level == 3) {
+    const char* e = getenv("DDP_HIP_TAU_MODE");
+    const int mode = e ? atoi(e) : 0;
+    if (mode == 1) hipLaunchKernelGGL((lin_static_tau_kernel<T, 1, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
+    else if (mode == 2) hipLaunchKernelGGL((lin_static_tau_kernel<T, 2, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
+    hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
+  }
+}
