@@ -717,7 +717,8 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
-        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
+        if (ctx->lin_static) lin_static_launch(ctx, p, 2);
+        else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
         if (ctx->lin_static) lin_static_launch(ctx, p, 3);
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 3>), dim3(blocks_for(BT * Pu)), dim3(LBS), 0, ctx->stream, p);
       } else {

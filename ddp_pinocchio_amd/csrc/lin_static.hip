@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "internal.h"
@@ -188,7 +189,7 @@ struct OutStage {
   double qdd[NV][LBS];          // [joint][lane]
   const double* in[4][LBS];     // fcol_1, fcol_2, diagonal column 1, diagonal column 2
   double* out[2][LBS];          // the point's column and its mirror image (or null)
-  int pi[LBS];                  // first perturbed direction (rows of f that see it directly)
+  int pi[LBS], pj[LBS];         // the perturbed directions (rows of f see an x direction directly)
 };
 
 template <int NV, bool UNIFORM_I>
@@ -218,6 +219,7 @@ __device__ __forceinline__ void offdiag_output(const LinParams& p, OutStage<NV>&
     S.out[0][lane] = valid ? tensor + (int64_t)idx_2 * n + (int64_t)idx_1 * n * L : nullptr;
     S.out[1][lane] = (valid && at_x_1 == at_x_2) ? tensor + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L : nullptr;
     S.pi[lane] = i;
+    S.pj[lane] = j;
   }
   __syncthreads();
   const int kk = lane % CH, esub = lane / CH;
@@ -239,11 +241,13 @@ __device__ __forceinline__ void offdiag_output(const LinParams& p, OutStage<NV>&
         const int e = (r0 + u) * EPI + esub;
         o0[u] = S.out[0][e];
         o1[u] = S.out[1][e];
-        const int ie = S.pi[e];
-        // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461); the second direction is a v or u one
-        const double xs = k == ie ? xk + eps : xk;
+        const int ie = S.pi[e], je = S.pj[e];
+        // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
+        double xs = k == ie ? xk + eps : xk;
+        if (k == je) xs = xs + eps;
         if (k < NV) {
-          const double xv = (NV + k) == ie ? xvk + eps : xvk;
+          double xv = (NV + k) == ie ? xvk + eps : xvk;
+          if (NV + k == je) xv = xv + eps;
           const double vo = dt * xv;
           fv[u] = xs + vo;
         } else {
@@ -415,6 +419,255 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   }
 }
 
+// ---- velocity level: the (q_i, v_j) and (v_i, v_j) points ----------------------------------------------------------
+// The evaluation is rbd::aba_vu_cached (velocity pass, bias-force pass, acceleration pass on the cached q-part), but
+// its first two passes are walked chain by chain (a chain = a run of single-child joints): down a chain computing the
+// link velocities, back up it forming the bias forces, so that only one chain's velocities are alive at a time; the
+// velocity of a branching joint is formed when its first child chain needs it.  The third pass recomputes the link
+// velocities on its way down instead of keeping 12 doubles per joint from the first.  u_i lives in LDS (the buffer the
+// output stage reads the accelerations from).
+template <class T> constexpr int n_children(int k) {
+  int c = 0;
+  for (int j = k + 1; j < T::N; ++j) if (T::parent[j] == k) ++c;
+  return c;
+}
+template <class T> constexpr bool chain_start(int k) { return T::parent[k] < 0 || T::parent[k] != k - 1 || n_children<T>(T::parent[k]) > 1; }
+template <class T> constexpr bool chain_end(int k) { return k == T::N - 1 || chain_start<T>(k + 1); }
+template <class T> constexpr int chain_first(int k) { while (!chain_start<T>(k)) --k; return k; }
+
+template <class T>
+struct VelState {
+  double vel[T::N][6];   // link velocities (a chain at a time, plus the branching joints)
+  double acc[T::N][6];   // bias-force accumulators, then link accelerations
+};
+
+template <int UQS_>
+struct VelCtx {
+  static constexpr int UQS = UQS_;   // stride between consecutive joints of this lane's u_i / acceleration buffer
+  const DevModel* m;
+  const double* __restrict__ qc;
+  const double* __restrict__ xg;
+  const double* __restrict__ ug;
+  double* uq;            // LDS: u_i, then the joint acceleration, of this lane (joint K at uq[K * UQS])
+  int i, j;              // perturbed directions (x indices; q directions do not change v)
+  double eps;
+};
+
+template <int NV, class C>
+__device__ __forceinline__ double lane_v(const C& c, int K) {
+  double v = c.xg[NV + K];
+  if (NV + K == c.i) v = v + c.eps;
+  if (NV + K == c.j) v = v + c.eps;
+  return v;
+}
+
+template <class T, int K, class C>
+__device__ __forceinline__ void joint_vel(const C& c, const double* vel_par, double* vel) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* E = c.qc + K * rbd::QC_STRIDE;
+  const double* r = E + 9;
+  const double* a = c.m->axis[K];
+  const double vK = lane_v<T::N>(c, K);
+  double vJ[6] = {0, 0, 0, 0, 0, 0};
+  vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+  if constexpr (T::parent[K] >= 0) rbd::xform_motion(E, r, vel_par, vel);
+  else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+}
+// velocity of joint K from the root (used for the branching joints)
+template <class T, int K, class C>
+__device__ __forceinline__ void vel_from_root(const C& c, double* vel) {
+  if constexpr (T::parent[K] >= 0) {
+    double vp[6];
+    vel_from_root<T, T::parent[K]>(c, vp);
+    joint_vel<T, K>(c, vp, vel);
+  } else {
+    joint_vel<T, K>(c, nullptr, vel);
+  }
+}
+template <class T, int K, class C>
+__device__ __forceinline__ void bias_force0(const C& c, const double* vel, double* pA) {
+  double Iv[6];
+  rbd::sym6_mv(c.m->I6[K], vel, Iv);
+  rbd::crf(vel, Iv, pA);
+}
+
+template <class T, int K, int E, class C>
+__device__ __forceinline__ void chain_down(const C& c, VelState<T>& s) {
+  if constexpr (T::parent[K] >= 0) joint_vel<T, K>(c, s.vel[T::parent[K]], s.vel[K]);
+  else joint_vel<T, K>(c, nullptr, s.vel[K]);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K < E) chain_down<T, K + 1, E>(c, s);
+}
+
+template <class T, int K, int F, class C>
+__device__ __forceinline__ void chain_up(const C& c, VelState<T>& s) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* E = c.qc + K * rbd::QC_STRIDE;
+  const double* r = E + 9;
+  const double* U = E + 12;
+  const double dinv = E[18];
+  const double* Ia = E + 19;
+  const double* a = c.m->axis[K];
+  double pAi[6];
+  if constexpr (has_child<T>(K)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pAi[k] = s.acc[K][k];
+  } else {
+    bias_force0<T, K>(c, s.vel[K], pAi);
+  }
+  double sp = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sp += a[k] * pAi[o + k];
+  const double ui = c.ug[K] - sp;
+  c.uq[K * C::UQS] = ui;
+  constexpr int par = T::parent[K];
+  if constexpr (par >= 0) {
+    const double vK = lane_v<T::N>(c, K);
+    double vJ[6] = {0, 0, 0, 0, 0, 0}, cb[6], pa[6], Iac[6], fp[6];
+    vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+    rbd::crm(s.vel[K], vJ, cb);
+    rbd::sym6_mv(Ia, cb, Iac);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
+    rbd::xform_force_T(E, r, pa, fp);
+    if constexpr (first_contrib<T>(K)) {
+      double p0[6];
+      bias_force0<T, par>(c, s.vel[par], p0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s.acc[par][k] = p0[k] + fp[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s.acc[par][k] += fp[k];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K > F) chain_up<T, K - 1, F>(c, s);
+}
+
+// chains in descending order of their joints: a chain is processed when the fold reaches its last joint
+template <class T, int K, class C>
+__device__ __forceinline__ void chain_at(const C& c, VelState<T>& s) {
+  if constexpr (chain_end<T>(K)) {
+    constexpr int F = chain_first<T>(K), P = T::parent[F];
+    if constexpr (P >= 0) {
+      // the largest-index child chain of a branching joint is the first to need (and to form) that joint's velocity
+      if constexpr (first_contrib<T>(F) && n_children<T>(P) > 1) vel_from_root<T, P>(c, s.vel[P]);
+    }
+    chain_down<T, F, K>(c, s);
+    chain_up<T, K, F>(c, s);
+  }
+}
+template <class T, class C, int... Ks>
+__device__ __forceinline__ void vel_up_all(const C& c, VelState<T>& s, std::integer_sequence<int, Ks...>) {
+  (chain_at<T, T::N - 1 - Ks>(c, s), ...);
+}
+
+// acceleration pass (rbd::aba_vu_cached, third loop), link velocities recomputed on the way
+template <class T, int K, class C>
+__device__ __forceinline__ void vel_down(const C& c, VelState<T>& s) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  constexpr int par = T::parent[K];
+  const double* E = c.qc + K * rbd::QC_STRIDE;
+  const double* r = E + 9;
+  const double* U = E + 12;
+  const double dinv = E[18];
+  const double* a = c.m->axis[K];
+  const double vK = lane_v<T::N>(c, K);
+  double vJ[6] = {0, 0, 0, 0, 0, 0}, vel[6], cb[6], ap[6];
+  vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+  if constexpr (par >= 0) {
+    rbd::xform_motion(E, r, s.vel[par], vel);
+    rbd::xform_motion(E, r, s.acc[par], ap);
+  } else {
+    const double a0[6] = {0, 0, 0, -c.m->gravity[0], -c.m->gravity[1], -c.m->gravity[2]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+    rbd::xform_motion(E, r, a0, ap);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+  rbd::crm(vel, vJ, cb);
+  double sum = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; sum += U[k] * ap[k]; }
+  const double qd = (c.uq[K * C::UQS] - sum) * dinv;
+  c.uq[K * C::UQS] = qd;
+  if constexpr (has_child<T>(K)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { s.vel[K][k] = vel[k]; s.acc[K][k] = ap[k]; }
+    s.acc[K][o] += a[0] * qd; s.acc[K][o + 1] += a[1] * qd; s.acc[K][o + 2] += a[2] * qd;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <class T, class C, int... Ks>
+__device__ __forceinline__ void vel_down_all(const C& c, VelState<T>& s, std::integer_sequence<int, Ks...>) {
+  (vel_down<T, Ks>(c, s), ...);
+}
+
+// One wave per group; the groups of one (instance, t):
+//   ROWS:  g < nv : (q_g, v_lane)      cfg 1+g   38 of 64 lanes, row-block output (+ mirror image)
+//   !ROWS: (v_i, v_j) pairs, cfg 0, 64 pairs per wave, generic output
+template <class T, bool ROWS>
+__global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
+  constexpr int nv = T::N, n = 2 * nv;
+  constexpr int TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS, G = ROWS ? nv : GU;
+  const int64_t bt = blockIdx.x / G;
+  const int g = (int)(blockIdx.x % G);
+  const int lane = threadIdx.x;
+  const int64_t Tn = p.d.T;
+  const int b = (int)(bt / Tn);
+  const int64_t t = bt % Tn;
+  int i, j, cfg;
+  bool valid;
+  if (ROWS) { i = g; j = nv + lane; cfg = 1 + g; valid = lane < nv; }
+  else {
+    const int pid = g * LBS + lane;
+    valid = pid < TRI;
+    tri_index(valid ? pid : 0, nv, i, j);
+    i += nv; j += nv; cfg = 0;
+  }
+  using Stage = typename std::conditional<ROWS, RowStage<nv>, OutStage<nv>>::type;
+  __shared__ Stage S;
+  VelCtx<ROWS ? 1 : LBS> c;
+  c.m = p.model;
+  c.qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
+  c.xg = p.x + ((int64_t)b * (Tn + 1) + t) * n;
+  c.ug = p.u + ((int64_t)b * Tn + t) * nv;
+  c.i = i; c.j = j;
+  c.eps = sqrt(sqrt(DBL_EPSILON));
+  // rows: lane-major with an odd stride (the layout the row-block output reads), idle lanes share the spare row;
+  // pairs: joint-major ([joint][lane]) for the generic output stage
+  if constexpr (ROWS) c.uq = S.q + (valid ? lane : nv) * (nv + 1);
+  else c.uq = &S.qdd[0][lane];
+  const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
+  if (w == 0x7fc01234u) c.eps = 0.0;     // never true in practice; orders the evaluation behind the warm-up
+  VelState<T> s;
+  vel_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+  vel_down_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+  __builtin_amdgcn_sched_barrier(0);
+  typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
+  const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const double dt = c.m->dt;
+  if constexpr (ROWS) {
+    double* fxx = kp->fxx + bt * n * n * n;
+    const double* fxb = kp->fx + bt * n * n;
+    rowblock_stage<nv>(S, lane, kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
+    __syncthreads();
+    // column (k, v_c) of slab q_i of f_xx: k + (nv + c) n + i n n; its mirror image: column q_i of slab v_c
+    rowblock_output<nv>(S, lane, i, nv, fxx + (int64_t)nv * n + (int64_t)i * n * n, fxx + (int64_t)i * n + (int64_t)nv * n * n, (int64_t)n * n,
+                        fxb + (int64_t)nv * n, fxx + (int64_t)nv * n + (int64_t)nv * n * n, (int64_t)n + (int64_t)n * n, dt);
+  } else {
+    LinParams po;
+    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
+    offdiag_output<nv, false>(po, S, valid, i, j, bt, c.xg, dt);
+  }
+}
+
 }  // namespace
 
 bool lin_static_supported(const DevModel& m) { return topo_matches<TopoTalos38>(m); }
@@ -431,5 +684,8 @@ void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
     else if (mode == 2) hipLaunchKernelGGL((lin_static_tau_kernel<T, 2, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     else hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
+  } else if (level == 2) {
+    hipLaunchKernelGGL((lin_static_vel_kernel<T, true>), dim3((unsigned)(BT * nv)), dim3(LBS), 0, ctx->stream, p);
+    hipLaunchKernelGGL((lin_static_vel_kernel<T, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
   }
 }
