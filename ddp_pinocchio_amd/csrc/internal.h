@@ -105,6 +105,8 @@ struct ddp_hip_ctx {
   double* eq_ws = nullptr;     // constraint-chain workspace (large models)
   double* lin_ws = nullptr;
   size_t lin_ws_bytes = 0;
+  double* lin_qws = nullptr;   // configuration-level workspace of the static path, lin_qws_bt (instance, t) pairs at a time
+  int64_t lin_qws_bt = 0;
   bool lin_static = false;     // the model's tree matches a compiled-in topology (lin_static.hip)
 
   bool profile = false;

@@ -716,7 +716,8 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
-        hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
+        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CFG") == nullptr) lin_static_launch(ctx, p, 1);
+        else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
         if (ctx->lin_static) lin_static_launch(ctx, p, 2);
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
         if (ctx->lin_static) lin_static_launch(ctx, p, 3);
@@ -791,6 +792,11 @@ int lin_setup(ddp_hip_ctx* ctx) {
     HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));
   }
   ctx->lin_static = want && lin_static_supported(ctx->model_h) && getenv("DDP_HIP_NO_STATIC") == nullptr;
+  if (ctx->lin_static) {
+    const int64_t BT = ctx->d.batch * ctx->d.T;
+    ctx->lin_qws_bt = BT < 1024 ? BT : 1024;
+    HIP_TRY(hipMalloc(&ctx->lin_qws, sizeof(double) * (size_t)(ctx->lin_qws_bt * lin_static_ws_per_bt(ctx->model_h))));
+  }
   // look-ahead states / jacobians of the constraint chain on large models
   if (ctx->d.Etot > 0 && ctx->d.nv > 6) {
     const Dims& d = ctx->d;
@@ -801,6 +807,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
   return DDP_HIP_OK;
 }
 void lin_teardown(ddp_hip_ctx* ctx) {
+  if (ctx->lin_qws) (void)hipFree(ctx->lin_qws);
   if (ctx->eq_ws) (void)hipFree(ctx->eq_ws);
   if (ctx->lin_ws) (void)hipFree(ctx->lin_ws);
 }

@@ -24,3 +24,4 @@ constexpr int LBS = 64;
 // topology; the launcher covers the velocity- and torque-level stencil points of finite_diff_hessian_compute mode 2
 bool lin_static_supported(const DevModel& m);
 void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level);
+int64_t lin_static_ws_per_bt(const DevModel& m);

@@ -668,9 +668,275 @@ __global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
   }
 }
 
+// ---- configuration level: the (q_i, q_j) points ---------------------------------------------------------------------
+// Every point has its own configuration, so the whole articulated-body algorithm runs per lane (rbd::aba_tree): the
+// chain-wise sweep of the velocity level, with the articulated inertias accumulated alongside the bias forces.  Only
+// the placements of joints i and j differ from the base configuration: each lane fetches those two from the q-cache of
+// configurations 1+i and 1+j once, everything else comes through the scalar path.  What the third pass needs from the
+// second (U, 1/D, u: 8 doubles per joint) does not fit in registers or LDS; it goes through a per-wave workspace,
+// written and read back once, 512-byte coalesced rows.
+constexpr int WS_PER_JOINT = 8;
+
+template <class T>
+struct CfgState {
+  double vel[T::N][6];
+  double accP[T::N][6];
+  double accI[T::N][21];
+  double w[2][WS_PER_JOINT];   // third pass: workspace values of the current / next joint
+};
+
+struct CfgCtx {
+  const DevModel* __restrict__ m;
+  const double* __restrict__ qc0;   // q-cache of the base configuration
+  const double* __restrict__ xg;
+  const double* __restrict__ ug;
+  double* __restrict__ W;           // this lane's column of the wave's workspace: (K, e) at W[(K * 8 + e) * LBS]
+  double* lvel;                     // LDS: link velocities of the chain being swept, (slot, k) at lvel[(slot * 6 + k) * LBS]
+  int i, j;
+};
+
+template <int K, int NV>
+__device__ __forceinline__ void lane_placement(const CfgCtx& c, double* P) {
+  // E | r of joint K at q_K and at q_K + eps (configuration 1+K of the q-cache): both wave-uniform, selected per lane
+  const double* base = c.qc0 + K * rbd::QC_STRIDE;
+  const double* pert = c.qc0 + ((int64_t)(1 + K) * NV + K) * rbd::QC_STRIDE;
+  const bool own = K == c.i || K == c.j;
+#pragma unroll
+  for (int e = 0; e < 12; ++e) P[e] = own ? pert[e] : base[e];
+}
+
+template <class T, int K>
+__device__ __forceinline__ void cfg_joint_vel(const CfgCtx& c, const double* P, const double* vel_par, double* vel) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* a = c.m->axis[K];
+  const double vK = c.xg[T::N + K];
+  double vJ[6] = {0, 0, 0, 0, 0, 0};
+  vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+  if constexpr (T::parent[K] >= 0) rbd::xform_motion(P, P + 9, vel_par, vel);
+  else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+}
+template <class T, int K>
+__device__ __forceinline__ void cfg_vel_from_root(const CfgCtx& c, double* vel) {
+  double P[12];
+  lane_placement<K, T::N>(c, P);
+  if constexpr (T::parent[K] >= 0) {
+    double vp[6];
+    cfg_vel_from_root<T, T::parent[K]>(c, vp);
+    cfg_joint_vel<T, K>(c, P, vp, vel);
+  } else {
+    cfg_joint_vel<T, K>(c, P, nullptr, vel);
+  }
+}
+template <int K>
+__device__ __forceinline__ void cfg_bias_force0(const CfgCtx& c, const double* vel, double* pA) {
+  double Iv[6];
+  rbd::sym6_mv(c.m->I6[K], vel, Iv);
+  rbd::crf(vel, Iv, pA);
+}
+
+// the link velocities of a chain go to LDS slot (K - F); `cur` carries the velocity of the previous joint
+template <class T, int K, int F, int E>
+__device__ __forceinline__ void cfg_chain_down(const CfgCtx& c, CfgState<T>& s, double* cur) {
+  double P[12], vel[6];
+  lane_placement<K, T::N>(c, P);
+  if constexpr (T::parent[K] >= 0) cfg_joint_vel<T, K>(c, P, cur, vel);
+  else cfg_joint_vel<T, K>(c, P, nullptr, vel);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { cur[k] = vel[k]; c.lvel[((K - F) * 6 + k) * LBS] = vel[k]; }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K < E) cfg_chain_down<T, K + 1, F, E>(c, s, cur);
+}
+template <class T, int K, int F>
+__device__ __forceinline__ void chain_vel_load(const CfgCtx& c, const CfgState<T>& s, double* vel) {
+  if constexpr (K >= F) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] = c.lvel[((K - F) * 6 + k) * LBS];
+  } else {   // the joint the chain hangs from: a branching joint, kept in registers
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] = s.vel[K][k];
+  }
+}
+
+// leaf -> root step of joint K (rbd::aba_tree, second loop)
+template <class T, int K, int F>
+__device__ __forceinline__ void cfg_chain_up(const CfgCtx& c, CfgState<T>& s) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* a = c.m->axis[K];
+  double IA[21], pAi[6], U[6], velK[6];
+  chain_vel_load<T, K, F>(c, s, velK);
+  if constexpr (has_child<T>(K)) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA[k] = s.accI[K][k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pAi[k] = s.accP[K][k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA[k] = c.m->I6[K][k];
+    cfg_bias_force0<K>(c, velK, pAi);
+  }
+  double d = 0, sp = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) U[r] = IA[rbd::sidx(r, o)] * a[0] + IA[rbd::sidx(r, o + 1)] * a[1] + IA[rbd::sidx(r, o + 2)] * a[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { d += a[k] * U[o + k]; sp += a[k] * pAi[o + k]; }
+  const double dinv = 1.0 / d;
+  const double ui = c.ug[K] - sp;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) c.W[(K * WS_PER_JOINT + k) * LBS] = U[k];
+  c.W[(K * WS_PER_JOINT + 6) * LBS] = dinv;
+  c.W[(K * WS_PER_JOINT + 7) * LBS] = ui;
+  constexpr int par = T::parent[K];
+  if constexpr (par >= 0) {
+    double P[12], Ia[21], vJ[6] = {0, 0, 0, 0, 0, 0}, cb[6], pa[6], Iac[6], fp[6];
+    lane_placement<K, T::N>(c, P);
+    const double vK = c.xg[T::N + K];
+    vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = 0; cc <= r; ++cc) Ia[rbd::sidx(r, cc)] = IA[rbd::sidx(r, cc)] - U[r] * U[cc] * dinv;
+    rbd::crm(velK, vJ, cb);
+    rbd::sym6_mv(Ia, cb, Iac);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
+    if constexpr (first_contrib<T>(K)) {
+      double velP[6];
+      chain_vel_load<T, par, F>(c, s, velP);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) s.accI[par][k] = c.m->I6[par][k];
+      cfg_bias_force0<par>(c, velP, s.accP[par]);
+    }
+    rbd::add_xtix(P, P + 9, Ia, s.accI[par]);
+    rbd::xform_force_T(P, P + 9, pa, fp);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s.accP[par][k] += fp[k];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K > F) cfg_chain_up<T, K - 1, F>(c, s);
+}
+
+template <class T, int K>
+__device__ __forceinline__ void cfg_chain_at(const CfgCtx& c, CfgState<T>& s) {
+  if constexpr (chain_end<T>(K)) {
+    constexpr int F = chain_first<T>(K), P = T::parent[F];
+    if constexpr (P >= 0) {
+      if constexpr (first_contrib<T>(F) && n_children<T>(P) > 1) cfg_vel_from_root<T, P>(c, s.vel[P]);
+    }
+    double cur[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (P >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cur[k] = s.vel[P][k];
+    }
+    cfg_chain_down<T, F, F, K>(c, s, cur);
+    cfg_chain_up<T, K, F>(c, s);
+  }
+}
+template <class T, int... Ks>
+__device__ __forceinline__ void cfg_up_all(const CfgCtx& c, CfgState<T>& s, std::integer_sequence<int, Ks...>) {
+  (cfg_chain_at<T, T::N - 1 - Ks>(c, s), ...);
+}
+
+// acceleration pass (rbd::aba_tree, third loop); link velocities recomputed, (U, 1/D, u) read back one joint ahead
+template <class T, int K>
+__device__ __forceinline__ void cfg_down(const CfgCtx& c, CfgState<T>& s, double* uq) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  constexpr int par = T::parent[K];
+  if constexpr (K + 1 < T::N) {
+#pragma unroll
+    for (int e = 0; e < WS_PER_JOINT; ++e) s.w[(K + 1) & 1][e] = c.W[((K + 1) * WS_PER_JOINT + e) * LBS];
+  }
+  const double* U = s.w[K & 1];
+  const double dinv = s.w[K & 1][6], ui = s.w[K & 1][7];
+  const double* a = c.m->axis[K];
+  const double vK = c.xg[T::N + K];
+  double P[12], vJ[6] = {0, 0, 0, 0, 0, 0}, vel[6], cb[6], ap[6];
+  lane_placement<K, T::N>(c, P);
+  vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+  if constexpr (par >= 0) {
+    rbd::xform_motion(P, P + 9, s.vel[par], vel);
+    rbd::xform_motion(P, P + 9, s.accP[par], ap);
+  } else {
+    const double a0[6] = {0, 0, 0, -c.m->gravity[0], -c.m->gravity[1], -c.m->gravity[2]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+    rbd::xform_motion(P, P + 9, a0, ap);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+  rbd::crm(vel, vJ, cb);
+  double sum = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; sum += U[k] * ap[k]; }
+  const double qd = (ui - sum) * dinv;
+  uq[K * LBS] = qd;
+  if constexpr (has_child<T>(K)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { s.vel[K][k] = vel[k]; s.accP[K][k] = ap[k]; }
+    s.accP[K][o] += a[0] * qd; s.accP[K][o + 1] += a[1] * qd; s.accP[K][o + 2] += a[2] * qd;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <class T, int... Ks>
+__device__ __forceinline__ void cfg_down_all(const CfgCtx& c, CfgState<T>& s, double* uq, std::integer_sequence<int, Ks...>) {
+  (cfg_down<T, Ks>(c, s, uq), ...);
+}
+
+// One wave = 64 (q_i, q_j) pairs, i < j.  The pointers the evaluation reads through are separate restrict-qualified
+// arguments: the workspace stores must not turn the scalar operand loads that follow them into per-lane loads.
+template <class T>
+__global__ __launch_bounds__(LBS) void lin_static_cfg_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ qcache,
+                                                             const double* __restrict__ xs, const double* __restrict__ us,
+                                                             double* __restrict__ ws, int64_t bt0) {
+  constexpr int nv = T::N, n = 2 * nv;
+  constexpr int TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS;
+  const int64_t bt = bt0 + blockIdx.x / GU;
+  const int g = (int)(blockIdx.x % GU);
+  const int lane = threadIdx.x;
+  const int64_t Tn = p.d.T;
+  const int b = (int)(bt / Tn);
+  const int64_t t = bt % Tn;
+  const int pid = g * LBS + lane;
+  const bool valid = pid < TRI;
+  int i, j;
+  tri_index(valid ? pid : 0, nv, i, j);
+  constexpr int MAXCH = 8;             // longest chain of the compiled-in topologies
+  __shared__ union { OutStage<nv> out; double vel[MAXCH * 6 * LBS]; } SH;
+  OutStage<nv>& S = SH.out;
+  CfgCtx c;
+  c.lvel = SH.vel + lane;
+  c.m = model;
+  c.qc0 = qcache + (bt * (nv + 1)) * (int64_t)nv * rbd::QC_STRIDE;
+  c.xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
+  c.ug = us + ((int64_t)b * Tn + t) * nv;
+  c.W = ws + (int64_t)blockIdx.x * (nv * WS_PER_JOINT * LBS) + lane;
+  c.i = i; c.j = j;
+  CfgState<T> s;
+  cfg_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+#pragma unroll
+  for (int e = 0; e < WS_PER_JOINT; ++e) s.w[0][e] = c.W[e * LBS];
+  cfg_down_all<T>(c, s, &S.qdd[0][lane], std::make_integer_sequence<int, nv>{});
+  __builtin_amdgcn_sched_barrier(0);
+  typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
+  const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  LinParams po;
+  po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
+  offdiag_output<nv, false>(po, S, valid, i, j, bt, c.xg, model->dt);
+}
+
 }  // namespace
 
 bool lin_static_supported(const DevModel& m) { return topo_matches<TopoTalos38>(m); }
+
+// doubles of workspace one (instance, t) needs at the configuration level
+int64_t lin_static_ws_per_bt(const DevModel& m) {
+  const int64_t nv = m.nv, TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS;
+  return GU * nv * WS_PER_JOINT * LBS;
+}
 
 // level 3: torque-level points (replaces lin_offdiag_kernel<NJ, 3>)
 void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
@@ -684,6 +950,14 @@ void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
     else if (mode == 2) hipLaunchKernelGGL((lin_static_tau_kernel<T, 2, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     else hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
+  } else if (level == 1) {
+    // in slices of (instance, t), so that the per-wave workspace stays small
+    const int64_t per = ctx->lin_qws_bt;
+    for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
+      const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
+      hipLaunchKernelGGL((lin_static_cfg_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u,
+                         ctx->lin_qws, bt0);
+    }
   } else if (level == 2) {
     hipLaunchKernelGGL((lin_static_vel_kernel<T, true>), dim3((unsigned)(BT * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_vel_kernel<T, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
