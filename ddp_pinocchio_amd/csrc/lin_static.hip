@@ -886,46 +886,69 @@ __device__ __forceinline__ void cfg_down_all(const CfgCtx& c, CfgState<T>& s, do
   (cfg_down<T, Ks>(c, s, uq), ...);
 }
 
-// One wave = 64 (q_i, q_j) pairs, i < j.  The pointers the evaluation reads through are separate restrict-qualified
-// arguments: the workspace stores must not turn the scalar operand loads that follow them into per-lane loads.
+// One wave = 64 (q_i, q_j) pairs, i < j, in two kernels: the fused velocity / articulated-inertia / bias-force sweep
+// (register hungry: one wave per SIMD), then the acceleration pass and the output stage (light: several waves per
+// SIMD hide the workspace reads).  The pointers the evaluation reads through are separate restrict-qualified arguments:
+// the workspace stores must not turn the scalar operand loads that follow them into per-lane loads.
 template <class T>
-__global__ __launch_bounds__(LBS) void lin_static_cfg_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ qcache,
-                                                             const double* __restrict__ xs, const double* __restrict__ us,
-                                                             double* __restrict__ ws, int64_t bt0) {
+__device__ __forceinline__ void cfg_setup(CfgCtx& c, const LinParams& p, const DevModel* __restrict__ model, const double* __restrict__ qcache,
+                                          const double* __restrict__ xs, const double* __restrict__ us, double* __restrict__ ws,
+                                          int64_t bt0, int64_t& bt, bool& valid) {
   constexpr int nv = T::N, n = 2 * nv;
   constexpr int TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS;
-  const int64_t bt = bt0 + blockIdx.x / GU;
+  bt = bt0 + blockIdx.x / GU;
   const int g = (int)(blockIdx.x % GU);
   const int lane = threadIdx.x;
   const int64_t Tn = p.d.T;
   const int b = (int)(bt / Tn);
   const int64_t t = bt % Tn;
   const int pid = g * LBS + lane;
-  const bool valid = pid < TRI;
-  int i, j;
-  tri_index(valid ? pid : 0, nv, i, j);
-  constexpr int MAXCH = 8;             // longest chain of the compiled-in topologies
-  __shared__ union { OutStage<nv> out; double vel[MAXCH * 6 * LBS]; } SH;
-  OutStage<nv>& S = SH.out;
-  CfgCtx c;
-  c.lvel = SH.vel + lane;
+  valid = pid < TRI;
+  tri_index(valid ? pid : 0, nv, c.i, c.j);
   c.m = model;
   c.qc0 = qcache + (bt * (nv + 1)) * (int64_t)nv * rbd::QC_STRIDE;
   c.xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
   c.ug = us + ((int64_t)b * Tn + t) * nv;
   c.W = ws + (int64_t)blockIdx.x * (nv * WS_PER_JOINT * LBS) + lane;
-  c.i = i; c.j = j;
+}
+
+template <class T>
+__global__ __launch_bounds__(LBS) void lin_static_cfg_up_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ qcache,
+                                                                const double* __restrict__ xs, const double* __restrict__ us,
+                                                                double* __restrict__ ws, int64_t bt0) {
+  constexpr int nv = T::N;
+  constexpr int MAXCH = 8;             // longest chain of the compiled-in topologies
+  __shared__ double s_vel[MAXCH * 6 * LBS];
+  CfgCtx c;
+  int64_t bt;
+  bool valid;
+  cfg_setup<T>(c, p, model, qcache, xs, us, ws, bt0, bt, valid);
+  c.lvel = s_vel + threadIdx.x;
   CfgState<T> s;
   cfg_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+}
+
+template <class T>
+__global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ qcache,
+                                                                  const double* __restrict__ xs, const double* __restrict__ us,
+                                                                  double* __restrict__ ws, int64_t bt0) {
+  constexpr int nv = T::N;
+  __shared__ OutStage<nv> S;
+  CfgCtx c;
+  int64_t bt;
+  bool valid;
+  cfg_setup<T>(c, p, model, qcache, xs, us, ws, bt0, bt, valid);
+  c.lvel = nullptr;
+  CfgState<T> s;
 #pragma unroll
   for (int e = 0; e < WS_PER_JOINT; ++e) s.w[0][e] = c.W[e * LBS];
-  cfg_down_all<T>(c, s, &S.qdd[0][lane], std::make_integer_sequence<int, nv>{});
+  cfg_down_all<T>(c, s, &S.qdd[0][threadIdx.x], std::make_integer_sequence<int, nv>{});
   __builtin_amdgcn_sched_barrier(0);
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   LinParams po;
   po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
-  offdiag_output<nv, false>(po, S, valid, i, j, bt, c.xg, model->dt);
+  offdiag_output<nv, false>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
 }
 
 }  // namespace
@@ -955,7 +978,9 @@ void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
     const int64_t per = ctx->lin_qws_bt;
     for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
       const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
-      hipLaunchKernelGGL((lin_static_cfg_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u,
+      hipLaunchKernelGGL((lin_static_cfg_up_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u,
+                         ctx->lin_qws, bt0);
+      hipLaunchKernelGGL((lin_static_cfg_down_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u,
                          ctx->lin_qws, bt0);
     }
   } else if (level == 2) {
