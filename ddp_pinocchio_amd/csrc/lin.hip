@@ -700,11 +700,23 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
   const int fd_mode = ctx->model_h.fd_mode;
   const bool small = NJ <= 6;
   if (stages & DDP_HIP_LIN_COST) hipLaunchKernelGGL(lin_cost_kernel, dim3((unsigned)BT), dim3(64), 0, ctx->stream, p);
+  // static-topology path: the q- / v-caches of the mode-2 stencil also serve the first order (base configuration and
+  // base (q, v)), so they are built ahead of whichever stage comes first
+  bool caches_built = false;
+  auto build_caches = [&]() {
+    if (caches_built || !p.qcache) return;
+    const int nv = (int)d.nv;
+    hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
+    hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
+    caches_built = true;
+  };
   if (stages & DDP_HIP_LIN_FIRST) {
     prof_begin(ctx, DDP_HIP_K_LIN_FIRST);
     hipLaunchKernelGGL((lin_base_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
-    if (ctx->model_h.first_order_fd)
-      hipLaunchKernelGGL((lin_first_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
+    if (ctx->model_h.first_order_fd) {
+      if (ctx->lin_static && fd_mode == 2 && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); lin_static_launch(ctx, p, 0); }
+      else hipLaunchKernelGGL((lin_first_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
+    }
     prof_end(ctx, DDP_HIP_K_LIN_FIRST);
   }
   if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors) {
@@ -713,8 +725,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
       if (p.qcache) {
         const int nv = (int)d.nv;
         const int64_t TRI = (int64_t)nv * (nv - 1) / 2, Pv = (int64_t)nv * nv + TRI, Pu = 2 * (int64_t)nv * nv + TRI;
-        hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
-        hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
+        build_caches();
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CFG") == nullptr) lin_static_launch(ctx, p, 1);
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);

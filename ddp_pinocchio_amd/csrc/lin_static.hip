@@ -693,13 +693,15 @@ struct CfgCtx {
   double* __restrict__ W;           // this lane's column of the wave's workspace: (K, e) at W[(K * 8 + e) * LBS]
   double* lvel;                     // LDS: link velocities of the chain being swept, (slot, k) at lvel[(slot * 6 + k) * LBS]
   int i, j;
+  const double* own;                // null: joints i, j take E | r from configurations 1+i, 1+j of the q-cache;
+                                    // else this lane's own E | r of joint i (first order: a step the cache does not hold)
 };
 
 template <int K, int NV>
 __device__ __forceinline__ void lane_placement(const CfgCtx& c, double* P) {
   // E | r of joint K at q_K and at q_K + eps (configuration 1+K of the q-cache): both wave-uniform, selected per lane
   const double* base = c.qc0 + K * rbd::QC_STRIDE;
-  const double* pert = c.qc0 + ((int64_t)(1 + K) * NV + K) * rbd::QC_STRIDE;
+  const double* pert = c.own ? c.own : c.qc0 + ((int64_t)(1 + K) * NV + K) * rbd::QC_STRIDE;
   const bool own = K == c.i || K == c.j;
 #pragma unroll
   for (int e = 0; e < 12; ++e) P[e] = own ? pert[e] : base[e];
@@ -842,8 +844,13 @@ __device__ __forceinline__ void cfg_up_all(const CfgCtx& c, CfgState<T>& s, std:
 }
 
 // acceleration pass (rbd::aba_tree, third loop); link velocities recomputed, (U, 1/D, u) read back one joint ahead
-template <class T, int K>
-__device__ __forceinline__ void cfg_down(const CfgCtx& c, CfgState<T>& s, double* uq) {
+// where the acceleration pass leaves joint K's acceleration: uq[K * STRIDE] (STRIDE = LBS: [joint][lane] rows of the
+// pair output stage; STRIDE = 1: this lane's own row)
+template <int STRIDE_>
+struct CfgDownOut { double* uq; static constexpr int STRIDE = STRIDE_; };
+
+template <class T, int K, class O>
+__device__ __forceinline__ void cfg_down(const CfgCtx& c, CfgState<T>& s, const O& out) {
   constexpr int o = T::prismatic[K] ? 3 : 0;
   constexpr int par = T::parent[K];
   if constexpr (K + 1 < T::N) {
@@ -873,7 +880,7 @@ __device__ __forceinline__ void cfg_down(const CfgCtx& c, CfgState<T>& s, double
 #pragma unroll
   for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; sum += U[k] * ap[k]; }
   const double qd = (ui - sum) * dinv;
-  uq[K * LBS] = qd;
+  out.uq[K * (O::STRIDE == LBS ? LBS : 1)] = qd;
   if constexpr (has_child<T>(K)) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) { s.vel[K][k] = vel[k]; s.accP[K][k] = ap[k]; }
@@ -881,9 +888,9 @@ __device__ __forceinline__ void cfg_down(const CfgCtx& c, CfgState<T>& s, double
   }
   __builtin_amdgcn_sched_barrier(0);
 }
-template <class T, int... Ks>
-__device__ __forceinline__ void cfg_down_all(const CfgCtx& c, CfgState<T>& s, double* uq, std::integer_sequence<int, Ks...>) {
-  (cfg_down<T, Ks>(c, s, uq), ...);
+template <class T, class O, int... Ks>
+__device__ __forceinline__ void cfg_down_all(const CfgCtx& c, CfgState<T>& s, const O& out, std::integer_sequence<int, Ks...>) {
+  (cfg_down<T, Ks>(c, s, out), ...);
 }
 
 // One wave = 64 (q_i, q_j) pairs, i < j, in two kernels: the fused velocity / articulated-inertia / bias-force sweep
@@ -910,6 +917,7 @@ __device__ __forceinline__ void cfg_setup(CfgCtx& c, const LinParams& p, const D
   c.xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
   c.ug = us + ((int64_t)b * Tn + t) * nv;
   c.W = ws + (int64_t)blockIdx.x * (nv * WS_PER_JOINT * LBS) + lane;
+  c.own = nullptr;
 }
 
 template <class T>
@@ -942,13 +950,106 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, c
   CfgState<T> s;
 #pragma unroll
   for (int e = 0; e < WS_PER_JOINT; ++e) s.w[0][e] = c.W[e * LBS];
-  cfg_down_all<T>(c, s, &S.qdd[0][threadIdx.x], std::make_integer_sequence<int, nv>{});
+  CfgDownOut<LBS> o{&S.qdd[0][threadIdx.x]};
+  cfg_down_all<T>(c, s, o, std::make_integer_sequence<int, nv>{});
   __builtin_amdgcn_sched_barrier(0);
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   LinParams po;
   po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
   offdiag_output<nv, false>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
+}
+
+// ---- first order: forward differences of f (problem.hpp:105-126 stepping, eps = sqrt(DBL_EPSILON)) -------------------
+// Three waves per (instance, t): lane d < nv perturbs q_d (LEVEL 1, full evaluation with its own placement of joint
+// d), v_d (LEVEL 2, velocity level on the base configuration) or u_d (LEVEL 3, torque level on the base (q, v)).
+// Column d of f_x / f_u is (f(x + eps e_d) - f(x)) / eps; the nv columns of a wave are one contiguous block.
+template <int NV>
+__device__ __forceinline__ void first_output(const double* q /* LDS, lane-major, stride NV + 1 */, int lane, int d0, double* __restrict__ out,
+                                             const double* __restrict__ f0, const double* __restrict__ xg, double dt, double eps) {
+  constexpr int n = 2 * NV, TOT = NV * n;
+  for (int e = lane; e < TOT; e += LBS) {
+    const int c = e / n, k = e - c * n;
+    const int d = d0 + c;                        // perturbed direction of this column (an x index, or >= n for u)
+    double xk = xg[k];
+    if (k == d) xk = xk + eps;
+    double fv;
+    if (k < NV) {
+      double xv = xg[NV + k];
+      if (NV + k == d) xv = xv + eps;
+      const double vo = dt * xv;
+      fv = xk + vo;
+    } else {
+      fv = xk + q[c * (NV + 1) + (k - NV)] * dt;
+    }
+    out[e] = (fv - f0[k]) / eps;
+  }
+}
+
+template <class T, int LEVEL>
+__global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ qcache,
+                                                               const double* __restrict__ xs, const double* __restrict__ us,
+                                                               double* __restrict__ ws, int64_t bt0) {
+  constexpr int nv = T::N, n = 2 * nv;
+  const int64_t bt = bt0 + blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t Tn = p.d.T;
+  const int b = (int)(bt / Tn);
+  const int64_t t = bt % Tn;
+  const bool valid = lane < nv;
+  const double eps = sqrt(DBL_EPSILON);
+  const double* __restrict__ qc0 = qcache + (bt * (nv + 1)) * (int64_t)nv * rbd::QC_STRIDE;
+  const double* __restrict__ xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
+  const double* __restrict__ ug = us + ((int64_t)b * Tn + t) * nv;
+  __shared__ double s_q[(nv + 1) * (nv + 1)];
+  double* uq = s_q + (valid ? lane : nv) * (nv + 1);
+  if constexpr (LEVEL == 3) {
+    const double* __restrict__ vc = p.vcache + (bt * (2 * nv + 1)) * (int64_t)nv * rbd::VC_STRIDE;
+    TauState<T> s;
+    auto tau = [&](int k) { double v = ug[k]; if (k == lane) v = v + eps; return v; };
+    tau_up_all<T>(*model, qc0, vc, tau, s, std::make_integer_sequence<int, nv>{});
+    tau_down_all<T>(*model, qc0, vc, s, std::make_integer_sequence<int, nv>{});
+#pragma unroll
+    for (int k = 0; k < nv; ++k) uq[k] = s.uu[k];
+  } else if constexpr (LEVEL == 2) {
+    VelCtx<1> c;
+    c.m = model; c.qc = qc0; c.xg = xg; c.ug = ug; c.uq = uq;
+    c.i = nv + lane; c.j = -1; c.eps = eps;
+    VelState<T> s;
+    vel_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+    vel_down_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+  } else {
+    constexpr int MAXCH = 8;
+    __shared__ double s_vel[MAXCH * 6 * LBS];
+    __shared__ double s_own[12 * LBS];
+    {
+      double E[9], r[3];
+      const int jn = valid ? lane : 0;
+      rbd::joint_placement(*model, jn, xg[jn] + eps, E, r);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) s_own[lane * 12 + e] = E[e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) s_own[lane * 12 + 9 + e] = r[e];
+    }
+    CfgCtx c;
+    c.m = model; c.qc0 = qc0; c.xg = xg; c.ug = ug;
+    c.W = ws + (int64_t)blockIdx.x * (nv * WS_PER_JOINT * LBS) + lane;
+    c.lvel = s_vel + lane;
+    c.i = valid ? lane : 0; c.j = -1;
+    c.own = s_own + lane * 12;
+    CfgState<T> s;
+    cfg_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+#pragma unroll
+    for (int e = 0; e < WS_PER_JOINT; ++e) s.w[0][e] = c.W[e * LBS];
+    CfgDownOut<nv + 1> o{uq};
+    cfg_down_all<T>(c, s, o, std::make_integer_sequence<int, nv>{});
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
+  const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+  __syncthreads();
+  double* out = LEVEL == 3 ? kp->fu + bt * n * nv : kp->fx + bt * n * n + (LEVEL == 2 ? nv * n : 0);
+  first_output<nv>(s_q, lane, LEVEL == 1 ? 0 : (LEVEL == 2 ? nv : n), out, kp->f_val + bt * n, xg, model->dt, eps);
 }
 
 }  // namespace
@@ -973,6 +1074,14 @@ void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
     else if (mode == 2) hipLaunchKernelGGL((lin_static_tau_kernel<T, 2, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     else hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
+  } else if (level == 0) {
+    const int64_t per = ctx->lin_qws_bt * GU;     // one wave per (instance, t) uses one of the GU workspace slots of a slice entry
+    for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
+      const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
+      hipLaunchKernelGGL((lin_static_first_kernel<T, 1>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
+    }
+    hipLaunchKernelGGL((lin_static_first_kernel<T, 2>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+    hipLaunchKernelGGL((lin_static_first_kernel<T, 3>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
   } else if (level == 1) {
     // in slices of (instance, t), so that the per-wave workspace stays small
     const int64_t per = ctx->lin_qws_bt;
