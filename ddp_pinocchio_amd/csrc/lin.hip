@@ -726,7 +726,8 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         const int nv = (int)d.nv;
         const int64_t TRI = (int64_t)nv * (nv - 1) / 2, Pv = (int64_t)nv * nv + TRI, Pu = 2 * (int64_t)nv * nv + TRI;
         build_caches();
-        hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
+        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_DIAG") == nullptr) lin_static_launch(ctx, p, 4);
+        else hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CFG") == nullptr) lin_static_launch(ctx, p, 1);
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
         if (ctx->lin_static) lin_static_launch(ctx, p, 2);

@@ -964,10 +964,15 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, c
 // Three waves per (instance, t): lane d < nv perturbs q_d (LEVEL 1, full evaluation with its own placement of joint
 // d), v_d (LEVEL 2, velocity level on the base configuration) or u_d (LEVEL 3, torque level on the base (q, v)).
 // Column d of f_x / f_u is (f(x + eps e_d) - f(x)) / eps; the nv columns of a wave are one contiguous block.
-template <int NV>
+// DIAG: the same single-direction evaluations with eps = eps_mach^(1/4) give the diagonal second-order entries
+// (problem.hpp:192-222): column (d, d) of the tensor is 2 ((f(x + eps e_d) - f(x)) - eps f_col_d) / eps^2; `out` then
+// points at column (0, 0) of the level's tensor block, consecutive columns ostride apart, fcol at the level's first-order block
+template <int NV, bool DIAG>
 __device__ __forceinline__ void first_output(const double* q /* LDS, lane-major, stride NV + 1 */, int lane, int d0, double* __restrict__ out,
-                                             const double* __restrict__ f0, const double* __restrict__ xg, double dt, double eps) {
+                                             int64_t ostride, const double* __restrict__ fcol, const double* __restrict__ f0,
+                                             const double* __restrict__ xg, double dt, double eps) {
   constexpr int n = 2 * NV, TOT = NV * n;
+  const double eps2 = eps * eps;
   for (int e = lane; e < TOT; e += LBS) {
     const int c = e / n, k = e - c * n;
     const int d = d0 + c;                        // perturbed direction of this column (an x index, or >= n for u)
@@ -982,11 +987,18 @@ __device__ __forceinline__ void first_output(const double* q /* LDS, lane-major,
     } else {
       fv = xk + q[c * (NV + 1) + (k - NV)] * dt;
     }
-    out[e] = (fv - f0[k]) / eps;
+    if constexpr (DIAG) {
+      double df = fv - f0[k];
+      df -= eps * fcol[e];
+      df *= 2;
+      out[k + c * ostride] = df / eps2;
+    } else {
+      out[e] = (fv - f0[k]) / eps;
+    }
   }
 }
 
-template <class T, int LEVEL>
+template <class T, int LEVEL, bool DIAG>
 __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ qcache,
                                                                const double* __restrict__ xs, const double* __restrict__ us,
                                                                double* __restrict__ ws, int64_t bt0) {
@@ -997,7 +1009,7 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
   const int b = (int)(bt / Tn);
   const int64_t t = bt % Tn;
   const bool valid = lane < nv;
-  const double eps = sqrt(DBL_EPSILON);
+  const double eps = DIAG ? sqrt(sqrt(DBL_EPSILON)) : sqrt(DBL_EPSILON);
   const double* __restrict__ qc0 = qcache + (bt * (nv + 1)) * (int64_t)nv * rbd::QC_STRIDE;
   const double* __restrict__ xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
   const double* __restrict__ ug = us + ((int64_t)b * Tn + t) * nv;
@@ -1022,7 +1034,7 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
     constexpr int MAXCH = 8;
     __shared__ double s_vel[MAXCH * 6 * LBS];
     __shared__ double s_own[12 * LBS];
-    {
+    if constexpr (!DIAG) {
       double E[9], r[3];
       const int jn = valid ? lane : 0;
       rbd::joint_placement(*model, jn, xg[jn] + eps, E, r);
@@ -1036,7 +1048,7 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
     c.W = ws + (int64_t)blockIdx.x * (nv * WS_PER_JOINT * LBS) + lane;
     c.lvel = s_vel + lane;
     c.i = valid ? lane : 0; c.j = -1;
-    c.own = s_own + lane * 12;
+    c.own = DIAG ? nullptr : s_own + lane * 12;     // eps_mach^(1/4) steps are the ones the q-cache holds
     CfgState<T> s;
     cfg_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
 #pragma unroll
@@ -1048,8 +1060,15 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   __syncthreads();
-  double* out = LEVEL == 3 ? kp->fu + bt * n * nv : kp->fx + bt * n * n + (LEVEL == 2 ? nv * n : 0);
-  first_output<nv>(s_q, lane, LEVEL == 1 ? 0 : (LEVEL == 2 ? nv : n), out, kp->f_val + bt * n, xg, model->dt, eps);
+  double* fcol = LEVEL == 3 ? kp->fu + bt * n * nv : kp->fx + bt * n * n + (LEVEL == 2 ? nv * n : 0);
+  double* out = fcol;
+  int64_t ostride = n;
+  if constexpr (DIAG) {
+    // column (d, d): f_xx at d (n + n n), f_uu at d (n + n m)
+    if (LEVEL == 3) { out = kp->fuu + bt * n * nv * nv; ostride = n + (int64_t)n * nv; }
+    else { ostride = n + (int64_t)n * n; out = kp->fxx + bt * n * n * n + (LEVEL == 2 ? nv * ostride : 0); }
+  }
+  first_output<nv, DIAG>(s_q, lane, LEVEL == 1 ? 0 : (LEVEL == 2 ? nv : n), out, ostride, fcol, kp->f_val + bt * n, xg, model->dt, eps);
 }
 
 }  // namespace
@@ -1074,14 +1093,20 @@ void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
     else if (mode == 2) hipLaunchKernelGGL((lin_static_tau_kernel<T, 2, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     else hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
-  } else if (level == 0) {
+  } else if (level == 0 || level == 4) {          // 0: first order, 4: diagonal second-order entries
     const int64_t per = ctx->lin_qws_bt * GU;     // one wave per (instance, t) uses one of the GU workspace slots of a slice entry
     for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
       const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
-      hipLaunchKernelGGL((lin_static_first_kernel<T, 1>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
+      if (level == 0) hipLaunchKernelGGL((lin_static_first_kernel<T, 1, false>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
+      else hipLaunchKernelGGL((lin_static_first_kernel<T, 1, true>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
     }
-    hipLaunchKernelGGL((lin_static_first_kernel<T, 2>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
-    hipLaunchKernelGGL((lin_static_first_kernel<T, 3>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+    if (level == 0) {
+      hipLaunchKernelGGL((lin_static_first_kernel<T, 2, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+      hipLaunchKernelGGL((lin_static_first_kernel<T, 3, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+    } else {
+      hipLaunchKernelGGL((lin_static_first_kernel<T, 2, true>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+      hipLaunchKernelGGL((lin_static_first_kernel<T, 3, true>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+    }
   } else if (level == 1) {
     // in slices of (instance, t), so that the per-wave workspace stays small
     const int64_t per = ctx->lin_qws_bt;
