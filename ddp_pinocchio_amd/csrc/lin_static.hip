@@ -66,11 +66,12 @@ struct TauState {
 };
 
 // leaf -> root step of joint K for a new tau (rbd::aba_u_cached, first loop)
-template <class T, int K>
+// qc: the (E | r | U | 1/D) part of the q-cache, QS doubles per joint (the cache itself, or a copy of it in LDS)
+template <class T, int K, int QS>
 __device__ __forceinline__ void tau_up(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc,
                                        double tauK, TauState<T>& s) {
   constexpr int o = T::prismatic[K] ? 3 : 0;
-  const double* E = qc + K * rbd::QC_STRIDE;
+  const double* E = qc + K * QS;
   const double* r = E + 9;
   const double* U = E + 12;
   const double dinv = E[18];
@@ -105,15 +106,15 @@ __device__ __forceinline__ void tau_up(const DevModel& m, const double* __restri
       for (int k = 0; k < 6; ++k) s.acc[par][k] += fp[k];
     }
   }
-  __builtin_amdgcn_sched_barrier(0);   // keep the operand loads of the next joint out of this one: SGPRs would spill
+  if constexpr (QS == rbd::QC_STRIDE || (K % 2) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the operand loads of the next joint out of this one: SGPRs would spill
 }
 
 // root -> leaf step of joint K (rbd::aba_u_cached, second loop); leaves the joint acceleration in uu[K]
-template <class T, int K>
+template <class T, int K, int QS>
 __device__ __forceinline__ void tau_down(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc,
                                          TauState<T>& s) {
   constexpr int o = T::prismatic[K] ? 3 : 0;
-  const double* E = qc + K * rbd::QC_STRIDE;
+  const double* E = qc + K * QS;
   const double* r = E + 9;
   const double* U = E + 12;
   const double dinv = E[18];
@@ -136,18 +137,29 @@ __device__ __forceinline__ void tau_down(const DevModel& m, const double* __rest
     for (int k = 0; k < 6; ++k) s.acc[K][k] = ap[k];
     s.acc[K][o] += a[0] * qd; s.acc[K][o + 1] += a[1] * qd; s.acc[K][o + 2] += a[2] * qd;
   }
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (QS == rbd::QC_STRIDE || (K % 2) == 0) __builtin_amdgcn_sched_barrier(0);
 }
 
-template <class T, class TauFn, int... Ks>
+template <class T, int QS, class TauFn, int... Ks>
 __device__ __forceinline__ void tau_up_all(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc, TauFn tau,
                                            TauState<T>& s, std::integer_sequence<int, Ks...>) {
-  (tau_up<T, T::N - 1 - Ks>(m, qc, vc, tau(T::N - 1 - Ks), s), ...);
+  (tau_up<T, T::N - 1 - Ks, QS>(m, qc, vc, tau(T::N - 1 - Ks), s), ...);
 }
-template <class T, int... Ks>
+template <class T, int QS, int... Ks>
 __device__ __forceinline__ void tau_down_all(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc,
                                              TauState<T>& s, std::integer_sequence<int, Ks...>) {
-  (tau_down<T, Ks>(m, qc, vc, s), ...);
+  (tau_down<T, Ks, QS>(m, qc, vc, s), ...);
+}
+
+// copy of the (E | r | U | 1/D) part of a q-cache block in LDS, PS doubles per joint: the scalar path fills at about
+// 2 bytes per clock and CU, so operands that both tree passes need are read from LDS instead (as broadcast reads)
+constexpr int PS = 20;
+template <int NV>
+__device__ __forceinline__ void stage_placements(double* sp, const double* __restrict__ qc, int lane) {
+  for (int idx = lane; idx < NV * 19; idx += LBS) {
+    const int K = idx / 19, e = idx - K * 19;
+    sp[K * PS + e] = qc[K * rbd::QC_STRIDE + e];
+  }
 }
 
 // Pull a wave-uniform block into the L2 ahead of the scalar loads that walk it: 64 lanes x 16 bytes per KiB, all in
@@ -374,13 +386,21 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   const double* __restrict__ xg = p.x + ((int64_t)b * (Tn + 1) + t) * n;
   const double* __restrict__ ug = p.u + ((int64_t)b * Tn + t) * nv;
   const int iu = i - n, ju = j - n;
-  const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(qc, lane) ^ warm_block<nv * rbd::VC_STRIDE * 8>(vc, lane);
+  __shared__ double s_P[ROWS ? nv * PS : 1];
+  unsigned int w = warm_block<nv * rbd::VC_STRIDE * 8>(vc, lane);
+  if constexpr (ROWS) { stage_placements<nv>(s_P, qc, lane); __syncthreads(); }
+  else w ^= warm_block<nv * rbd::QC_STRIDE * 8>(qc, lane);
   if (w == 0x7fc01234u) eps = 0.0;     // never true for cache contents that are finite doubles in practice; orders the chain
   TauState<T> s;
   auto tau = [&](int k) { double v = ug[k]; if (k == iu) v = v + eps; if (k == ju) v = v + eps; return v; };
   if (MODE != 1) {
-    tau_up_all<T>(m, qc, vc, tau, s, std::make_integer_sequence<int, nv>{});
-    tau_down_all<T>(m, qc, vc, s, std::make_integer_sequence<int, nv>{});
+    if constexpr (ROWS) {
+      tau_up_all<T, PS>(m, s_P, vc, tau, s, std::make_integer_sequence<int, nv>{});
+      tau_down_all<T, PS>(m, s_P, vc, s, std::make_integer_sequence<int, nv>{});
+    } else {
+      tau_up_all<T, rbd::QC_STRIDE>(m, qc, vc, tau, s, std::make_integer_sequence<int, nv>{});
+      tau_down_all<T, rbd::QC_STRIDE>(m, qc, vc, s, std::make_integer_sequence<int, nv>{});
+    }
   } else {
     for (int k = 0; k < nv; ++k) s.uu[k] = tau(k);
   }
@@ -441,10 +461,12 @@ struct VelState {
   double acc[T::N][6];   // bias-force accumulators, then link accelerations
 };
 
-template <int UQS_>
+template <int UQS_, int QS_ = rbd::QC_STRIDE>
 struct VelCtx {
   static constexpr int UQS = UQS_;   // stride between consecutive joints of this lane's u_i / acceleration buffer
+  static constexpr int QS = QS_;     // doubles per joint of the (E | r | U | 1/D) block behind qp
   const DevModel* m;
+  const double* qp;                  // (E | r | U | 1/D): the q-cache block itself, or its copy in LDS
   const double* __restrict__ qc;
   const double* __restrict__ xg;
   const double* __restrict__ ug;
@@ -464,7 +486,7 @@ __device__ __forceinline__ double lane_v(const C& c, int K) {
 template <class T, int K, class C>
 __device__ __forceinline__ void joint_vel(const C& c, const double* vel_par, double* vel) {
   constexpr int o = T::prismatic[K] ? 3 : 0;
-  const double* E = c.qc + K * rbd::QC_STRIDE;
+  const double* E = c.qp + K * C::QS;
   const double* r = E + 9;
   const double* a = c.m->axis[K];
   const double vK = lane_v<T::N>(c, K);
@@ -507,11 +529,11 @@ __device__ __forceinline__ void chain_down(const C& c, VelState<T>& s) {
 template <class T, int K, int F, class C>
 __device__ __forceinline__ void chain_up(const C& c, VelState<T>& s) {
   constexpr int o = T::prismatic[K] ? 3 : 0;
-  const double* E = c.qc + K * rbd::QC_STRIDE;
+  const double* E = c.qp + K * C::QS;
   const double* r = E + 9;
   const double* U = E + 12;
   const double dinv = E[18];
-  const double* Ia = E + 19;
+  const double* Ia = c.qc + K * rbd::QC_STRIDE + 19;
   const double* a = c.m->axis[K];
   double pAi[6];
   if constexpr (has_child<T>(K)) {
@@ -572,7 +594,7 @@ template <class T, int K, class C>
 __device__ __forceinline__ void vel_down(const C& c, VelState<T>& s) {
   constexpr int o = T::prismatic[K] ? 3 : 0;
   constexpr int par = T::parent[K];
-  const double* E = c.qc + K * rbd::QC_STRIDE;
+  const double* E = c.qp + K * C::QS;
   const double* r = E + 9;
   const double* U = E + 12;
   const double dinv = E[18];
@@ -633,9 +655,11 @@ __global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
   }
   using Stage = typename std::conditional<ROWS, RowStage<nv>, OutStage<nv>>::type;
   __shared__ Stage S;
-  VelCtx<ROWS ? 1 : LBS> c;
+  VelCtx<ROWS ? 1 : LBS, ROWS ? PS : rbd::QC_STRIDE> c;
+  __shared__ double s_P[ROWS ? nv * PS : 1];
   c.m = p.model;
   c.qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
+  c.qp = ROWS ? s_P : c.qc;
   c.xg = p.x + ((int64_t)b * (Tn + 1) + t) * n;
   c.ug = p.u + ((int64_t)b * Tn + t) * nv;
   c.i = i; c.j = j;
@@ -646,6 +670,7 @@ __global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
   else c.uq = &S.qdd[0][lane];
   const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
   if (w == 0x7fc01234u) c.eps = 0.0;     // never true in practice; orders the evaluation behind the warm-up
+  if constexpr (ROWS) { stage_placements<nv>(s_P, c.qc, lane); __syncthreads(); }
   VelState<T> s;
   vel_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
   vel_down_all<T>(c, s, std::make_integer_sequence<int, nv>{});
@@ -1019,13 +1044,13 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
     const double* __restrict__ vc = p.vcache + (bt * (2 * nv + 1)) * (int64_t)nv * rbd::VC_STRIDE;
     TauState<T> s;
     auto tau = [&](int k) { double v = ug[k]; if (k == lane) v = v + eps; return v; };
-    tau_up_all<T>(*model, qc0, vc, tau, s, std::make_integer_sequence<int, nv>{});
-    tau_down_all<T>(*model, qc0, vc, s, std::make_integer_sequence<int, nv>{});
+    tau_up_all<T, rbd::QC_STRIDE>(*model, qc0, vc, tau, s, std::make_integer_sequence<int, nv>{});
+    tau_down_all<T, rbd::QC_STRIDE>(*model, qc0, vc, s, std::make_integer_sequence<int, nv>{});
 #pragma unroll
     for (int k = 0; k < nv; ++k) uq[k] = s.uu[k];
   } else if constexpr (LEVEL == 2) {
     VelCtx<1> c;
-    c.m = model; c.qc = qc0; c.xg = xg; c.ug = ug; c.uq = uq;
+    c.m = model; c.qc = qc0; c.qp = qc0; c.xg = xg; c.ug = ug; c.uq = uq;
     c.i = nv + lane; c.j = -1; c.eps = eps;
     VelState<T> s;
     vel_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
