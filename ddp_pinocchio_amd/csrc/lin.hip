@@ -706,8 +706,11 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
   auto build_caches = [&]() {
     if (caches_built || !p.qcache) return;
     const int nv = (int)d.nv;
-    hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
-    hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
+    if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CACHE") == nullptr) lin_static_launch(ctx, p, 5);
+    else {
+      hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
+      hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
+    }
     caches_built = true;
   };
   if (stages & DDP_HIP_LIN_FIRST) {

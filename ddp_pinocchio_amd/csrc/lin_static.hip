@@ -1096,6 +1096,251 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
   first_output<nv, DIAG>(s_q, lane, LEVEL == 1 ? 0 : (LEVEL == 2 ? nv : n), out, ostride, fcol, kp->f_val + bt * n, xg, model->dt, eps);
 }
 
+// ---- q- and v-caches ------------------------------------------------------------------------------------------------
+// lin_static_qvcache_kernel: one wave per (instance, t), lane c = configuration c of the mode-2 stencil (0: q, 1+i:
+// q + eps e_i).  The chain-wise sweep of the configuration level, reduced to what the caches hold: rbd::aba_qpart
+// (E | r | U | 1/D | Ia per joint) and, at the base velocity, rbd::aba_vpart_cached (cb | pA0 | Ia cb) -- v-cache entry 0
+// for the base configuration, nv+1+i for configuration 1+i.
+template <class T, int K>
+__device__ __forceinline__ void placement_static(const DevModel& m, double q, double* P) {
+  const double* Rp = m.Rp[K];
+  const double* a = m.axis[K];
+  double* E = P;
+  double* r = P + 9;
+  if constexpr (!T::prismatic[K]) {
+    double sn, cs;
+    sincos(q, &sn, &cs);
+    const double Kx[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+    double K2[9], RJ[9], Rc[9];
+    rbd::mm3(Kx, Kx, K2);
+    const double omc = 1.0 - cs;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) RJ[k] = sn * Kx[k] + omc * K2[k];
+    RJ[0] += 1.0; RJ[4] += 1.0; RJ[8] += 1.0;
+    rbd::mm3(Rp, RJ, Rc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) E[3 * k + l] = Rc[3 * l + k];
+    r[0] = m.pp[K][0]; r[1] = m.pp[K][1]; r[2] = m.pp[K][2];
+  } else {
+    const double dd[3] = {a[0] * q, a[1] * q, a[2] * q};
+    double Rd[3];
+    rbd::mv3(Rp, dd, Rd);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) E[3 * k + l] = Rp[3 * l + k];
+    r[0] = m.pp[K][0] + Rd[0]; r[1] = m.pp[K][1] + Rd[1]; r[2] = m.pp[K][2] + Rd[2];
+  }
+}
+
+struct QvCtx {
+  const DevModel* __restrict__ m;
+  const double* __restrict__ xg;
+  double* __restrict__ qc;     // this lane's q-cache block
+  double* __restrict__ vc;     // this lane's v-cache block
+  double* lvel;                // LDS: link velocities of the chain being swept
+  int jn;                      // joint whose position this lane steps (-1: none)
+  double eps;
+};
+template <class T>
+struct QvState {
+  double vel[T::N][6];
+  double accI[T::N][21];
+};
+template <class T, int K>
+__device__ __forceinline__ void qv_placement(const QvCtx& c, double* P) {
+  double q = c.xg[K];
+  if (K == c.jn) q = q + c.eps;
+  placement_static<T, K>(*c.m, q, P);
+}
+template <class T, int K>
+__device__ __forceinline__ void qv_joint_vel(const QvCtx& c, const double* P, const double* vel_par, double* vel) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* a = c.m->axis[K];
+  const double vK = c.xg[T::N + K];
+  double vJ[6] = {0, 0, 0, 0, 0, 0};
+  vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+  if constexpr (T::parent[K] >= 0) rbd::xform_motion(P, P + 9, vel_par, vel);
+  else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+}
+template <class T, int K>
+__device__ __forceinline__ void qv_vel_from_root(const QvCtx& c, double* vel) {
+  double P[12];
+  qv_placement<T, K>(c, P);
+  if constexpr (T::parent[K] >= 0) {
+    double vp[6];
+    qv_vel_from_root<T, T::parent[K]>(c, vp);
+    qv_joint_vel<T, K>(c, P, vp, vel);
+  } else {
+    qv_joint_vel<T, K>(c, P, nullptr, vel);
+  }
+}
+template <class T, int K, int F, int E>
+__device__ __forceinline__ void qv_chain_down(const QvCtx& c, double* cur) {
+  double P[12], vel[6];
+  qv_placement<T, K>(c, P);
+  if constexpr (T::parent[K] >= 0) qv_joint_vel<T, K>(c, P, cur, vel);
+  else qv_joint_vel<T, K>(c, P, nullptr, vel);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { cur[k] = vel[k]; c.lvel[((K - F) * 6 + k) * LBS] = vel[k]; }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K < E) qv_chain_down<T, K + 1, F, E>(c, cur);
+}
+template <class T, int K, int F>
+__device__ __forceinline__ void qv_chain_up(const QvCtx& c, QvState<T>& s) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* a = c.m->axis[K];
+  double P[12], IA[21], U[6], Ia[21], vel[6];
+  qv_placement<T, K>(c, P);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vel[k] = c.lvel[((K - F) * 6 + k) * LBS];
+  if constexpr (has_child<T>(K)) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA[k] = s.accI[K][k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA[k] = c.m->I6[K][k];
+  }
+  double d = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) U[r] = IA[rbd::sidx(r, o)] * a[0] + IA[rbd::sidx(r, o + 1)] * a[1] + IA[rbd::sidx(r, o + 2)] * a[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d += a[k] * U[o + k];
+  const double dinv = 1.0 / d;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int cc = 0; cc <= r; ++cc) Ia[rbd::sidx(r, cc)] = IA[rbd::sidx(r, cc)] - U[r] * U[cc] * dinv;
+  constexpr int par = T::parent[K];
+  if constexpr (par >= 0) {
+    if constexpr (first_contrib<T>(K)) {
+#pragma unroll
+      for (int k = 0; k < 21; ++k) s.accI[par][k] = c.m->I6[par][k];
+    }
+    rbd::add_xtix(P, P + 9, Ia, s.accI[par]);
+  }
+  // rbd::aba_vpart_cached at the base velocity
+  const double vK = c.xg[T::N + K];
+  double vJ[6] = {0, 0, 0, 0, 0, 0}, cb[6], pA[6], Iv[6], Iac[6];
+  vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+  rbd::crm(vel, vJ, cb);
+  rbd::sym6_mv(c.m->I6[K], vel, Iv);
+  rbd::crf(vel, Iv, pA);
+  rbd::sym6_mv(Ia, cb, Iac);
+  double* qo = c.qc + K * rbd::QC_STRIDE;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) qo[k] = P[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) qo[12 + k] = U[k];
+  qo[18] = dinv;
+#pragma unroll
+  for (int k = 0; k < 21; ++k) qo[19 + k] = Ia[k];
+  double* vo = c.vc + K * rbd::VC_STRIDE;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { vo[k] = cb[k]; vo[6 + k] = pA[k]; vo[12 + k] = Iac[k]; }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K > F) qv_chain_up<T, K - 1, F>(c, s);
+}
+template <class T, int K>
+__device__ __forceinline__ void qv_chain_at(const QvCtx& c, QvState<T>& s) {
+  if constexpr (chain_end<T>(K)) {
+    constexpr int F = chain_first<T>(K), P = T::parent[F];
+    double cur[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (P >= 0) {
+      if constexpr (first_contrib<T>(F) && n_children<T>(P) > 1) qv_vel_from_root<T, P>(c, s.vel[P]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cur[k] = s.vel[P][k];
+    }
+    qv_chain_down<T, F, F, K>(c, cur);
+    qv_chain_up<T, K, F>(c, s);
+  }
+}
+template <class T, int... Ks>
+__device__ __forceinline__ void qv_all(const QvCtx& c, QvState<T>& s, std::integer_sequence<int, Ks...>) {
+  (qv_chain_at<T, T::N - 1 - Ks>(c, s), ...);
+}
+
+template <class T>
+__global__ __launch_bounds__(LBS) void lin_static_qvcache_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ xs,
+                                                                 double* __restrict__ qcache, double* __restrict__ vcache) {
+  constexpr int nv = T::N, n = 2 * nv, MAXCH = 8;
+  const int64_t bt = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t Tn = p.d.T;
+  const int b = (int)(bt / Tn);
+  const int64_t t = bt % Tn;
+  __shared__ double s_vel[MAXCH * 6 * LBS];
+  if (lane > nv) return;                         // configurations 0 .. nv (no workgroup barrier below)
+  QvCtx c;
+  c.m = model;
+  c.xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
+  c.qc = qcache + (bt * (nv + 1) + lane) * (int64_t)nv * rbd::QC_STRIDE;
+  c.vc = vcache + (bt * (2 * nv + 1) + (lane == 0 ? 0 : nv + lane)) * (int64_t)nv * rbd::VC_STRIDE;
+  c.lvel = s_vel + lane;
+  c.jn = lane - 1;
+  c.eps = sqrt(sqrt(DBL_EPSILON));
+  QvState<T> s;
+  qv_all<T>(c, s, std::make_integer_sequence<int, nv>{});
+}
+
+// lin_static_vcache_kernel: v-cache entries 1 + i = (q, v + eps e_i): first pass of the ABA on the cached base q-part
+template <class T, int K>
+__device__ __forceinline__ void vc_joint(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ xg, int iv, double eps,
+                                         double (&vel)[T::N][6], double* __restrict__ vc) {
+  constexpr int o = T::prismatic[K] ? 3 : 0;
+  const double* E = qc + K * rbd::QC_STRIDE;
+  const double* r = E + 9;
+  const double* Ia = E + 19;
+  const double* a = m.axis[K];
+  double vK = xg[T::N + K];
+  if (K == iv) vK = vK + eps;
+  double vJ[6] = {0, 0, 0, 0, 0, 0}, v[6], cb[6], pA[6], Iv[6], Iac[6];
+  vJ[o] = a[0] * vK; vJ[o + 1] = a[1] * vK; vJ[o + 2] = a[2] * vK;
+  if constexpr (T::parent[K] >= 0) rbd::xform_motion(E, r, vel[T::parent[K]], v);
+  else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { v[k] += vJ[k]; vel[K][k] = v[k]; }
+  rbd::crm(v, vJ, cb);
+  rbd::sym6_mv(m.I6[K], v, Iv);
+  rbd::crf(v, Iv, pA);
+  rbd::sym6_mv(Ia, cb, Iac);
+  double* vo = vc + K * rbd::VC_STRIDE;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { vo[k] = cb[k]; vo[6 + k] = pA[k]; vo[12 + k] = Iac[k]; }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <class T, int... Ks>
+__device__ __forceinline__ void vc_all(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ xg, int iv, double eps,
+                                       double (&vel)[T::N][6], double* __restrict__ vc, std::integer_sequence<int, Ks...>) {
+  (vc_joint<T, Ks>(m, qc, xg, iv, eps, vel, vc), ...);
+}
+template <class T>
+__global__ __launch_bounds__(LBS) void lin_static_vcache_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ xs,
+                                                                const double* __restrict__ qcache, double* __restrict__ vcache) {
+  constexpr int nv = T::N, n = 2 * nv;
+  const int64_t bt = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t Tn = p.d.T;
+  const int b = (int)(bt / Tn);
+  const int64_t t = bt % Tn;
+  if (lane >= nv) return;
+  const double* __restrict__ qc = qcache + (bt * (nv + 1)) * (int64_t)nv * rbd::QC_STRIDE;
+  const double* __restrict__ xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
+  double* __restrict__ vc = vcache + (bt * (2 * nv + 1) + 1 + lane) * (int64_t)nv * rbd::VC_STRIDE;
+  double vel[nv][6];
+  vc_all<T>(*model, qc, xg, lane, sqrt(sqrt(DBL_EPSILON)), vel, vc, std::make_integer_sequence<int, nv>{});
+}
+
 }  // namespace
 
 bool lin_static_supported(const DevModel& m) { return topo_matches<TopoTalos38>(m); }
@@ -1118,6 +1363,9 @@ void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
     else if (mode == 2) hipLaunchKernelGGL((lin_static_tau_kernel<T, 2, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     else hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_tau_kernel<T, 0, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
+  } else if (level == 5) {                        // q- and v-caches
+    hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
+    hipLaunchKernelGGL((lin_static_vcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
   } else if (level == 0 || level == 4) {          // 0: first order, 4: diagonal second-order entries
     const int64_t per = ctx->lin_qws_bt * GU;     // one wave per (instance, t) uses one of the GU workspace slots of a slice entry
     for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
