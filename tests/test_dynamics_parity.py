@@ -224,3 +224,43 @@ def test_forward_line_search_floor(gpu):
         assert rc == capi.EV_LINESEARCH_FLOOR
         assert step[0] == 2.0 ** -34
         assert np.allclose(ctx.download("U_NEW", 0, 1)[0], 2.0 ** -33)
+
+
+@pytest.mark.gpu
+def test_static_vs_generic_linearisation_full_horizon(gpu, monkeypatch):
+    """The static-topology stencil kernels (lin_static.hip) against the generic run-time-tree kernels (lin.hip) at the
+    full horizon, with more (instance, t) pairs than one workspace slice holds (1 024): same stencil, same caches, the
+    same operation sequences up to the order of a few additions -- held to a few ulp of f amplified by 1 / eps^2."""
+    capi = gpu
+    T, B = 200, 6
+    model, spec, o = make("tree38", T, batch=B, fd_mode=2)
+    rng = np.random.default_rng(5)
+    us = 0.3 * rng.normal(size=(B, T * model.nv))
+    out = {}
+    for tag in ("static", "generic"):
+        if tag == "generic":
+            monkeypatch.setenv("DDP_HIP_NO_STATIC", "1")
+        with capi.Context(spec) as ctx:
+            ctx.upload("X", np.zeros((B, (T + 1) * 2 * model.nv)))
+            ctx.upload("U", us)
+            ctx.rollout()
+            ctx.linearize()
+            out[tag] = {k: ctx.download(s) for k, s in (("f_val", "F_VAL"), ("fx", "FX"), ("fu", "FU"))}
+            # the tensors are 1.2 GB per instance: compare instance by instance
+            for b in (0, B - 1):
+                for k, s in (("fxx", "FXX"), ("fux", "FUX"), ("fuu", "FUU")):
+                    out[tag][k, b] = ctx.download(s, b, 1)[0]
+    monkeypatch.delenv("DDP_HIP_NO_STATIC")
+    EPS, E1, E2 = 2.220446049250313e-16, 1.4901161193847656e-08, 1.220703125e-04
+    fscale = max(1.0, float(np.max(np.abs(out["generic"]["f_val"]))))
+    assert np.array_equal(out["static"]["f_val"], out["generic"]["f_val"])
+    for k in ("fx", "fu"):
+        err = float(np.max(np.abs(out["static"][k] - out["generic"][k])))
+        assert err <= 32 * EPS * fscale / E1, (k, err)      # FMA contraction differs with the code shape: a few ulp of f
+    for b in (0, B - 1):
+        for k in ("fxx", "fux", "fuu"):
+            a, g = out["static"][k, b], out["generic"][k, b]
+            assert np.all(np.isfinite(a))
+            err = float(np.max(np.abs(a - g)))
+            tol = 64 * EPS * fscale / (E2 * E2) + 4 * (32 * EPS * fscale / E1) / E2
+            assert err <= tol * max(1.0, float(np.max(np.abs(g)))), (k, b, err, tol)
