@@ -42,7 +42,8 @@ EXPORTS = [
     "ddp_hip_stream", "ddp_hip_synchronize", "ddp_hip_seq_size", "ddp_hip_device_ptr", "ddp_hip_upload",
     "ddp_hip_download", "ddp_hip_fill", "ddp_hip_rollout", "ddp_hip_linearize", "ddp_hip_linearize_stages",
     "ddp_hip_backward",
-    "ddp_hip_forward", "ddp_hip_cost_seq_aug", "ddp_hip_swap_traj", "ddp_hip_profile_enable",
+    "ddp_hip_forward", "ddp_hip_cost_seq_aug", "ddp_hip_swap_traj",
+    "ddp_hip_update_origin", "ddp_hip_optimality", "ddp_hip_update_multipliers", "ddp_hip_profile_enable",
     "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_comm_unique_id",
     "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_builtin_model",
 ]
@@ -113,6 +114,9 @@ def lib():
     L.ddp_hip_forward.argtypes = [C.c_void_p, _dp, C.c_int32, _dp, _dp]
     L.ddp_hip_cost_seq_aug.argtypes = [C.c_void_p, C.c_int, _dp]
     L.ddp_hip_swap_traj.argtypes = [C.c_void_p]
+    L.ddp_hip_update_origin.argtypes = [C.c_void_p, C.c_int]
+    L.ddp_hip_optimality.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    L.ddp_hip_update_multipliers.argtypes = [C.c_void_p, _dp]
     L.ddp_hip_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.ddp_hip_profile_reset.argtypes = [C.c_void_p]
     L.ddp_hip_profile_get.argtypes = [C.c_void_p, C.c_int, _dp, _lp]
@@ -280,6 +284,20 @@ class Context:
 
     def swap_traj(self):
         _check(lib().ddp_hip_swap_traj(self._h), "swap_traj")
+
+    def update_origin(self, which):
+        _check(lib().ddp_hip_update_origin(self._h, which), "update_origin")
+
+    def optimality(self, mu):
+        mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
+        obj = np.zeros(self.batch)
+        constr = np.zeros(self.batch)
+        _check(lib().ddp_hip_optimality(self._h, _ptr(mu), _ptr(obj), _ptr(constr)), "optimality")
+        return obj, constr
+
+    def update_multipliers(self, mu):
+        mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
+        _check(lib().ddp_hip_update_multipliers(self._h, _ptr(mu)), "update_multipliers")
 
     def profile_enable(self, on=True):
         _check(lib().ddp_hip_profile_enable(self._h, 1 if on else 0), "profile_enable")

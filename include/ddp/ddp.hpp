@@ -251,75 +251,18 @@ struct ddp_solver_t {   // ddp.hpp:300-869
     return step;
   }
 
-  // ---- outer loop (host side; ddp.hpp:516-523, 576-627, 642-696, 745-842; mat_seq_common.hpp:62-89) ---------------
-  void update_origin(affine_vector_function_seq_t<scalar_t>& a, trajectory_t const& traj) const {
-    auto const& idx = *a.m_val_data.m_idx;
-    for (index_t t = idx.index_begin(); t < idx.index_end(); ++t) {
-      index_t r = idx.rows(t);
-      scalar_t* org = a.m_origin[t].data();
-      scalar_t* val = a.m_val_data.data() + idx.offset(t);
-      const scalar_t* jac = a.m_jac_data.data() + idx.offset(t) * ndx;
-      const scalar_t* xn = traj.m_state_data.data() + t * nx;
-      for (index_t i = 0; i < r; ++i) {
-        scalar_t s = 0;
-        for (index_t l = 0; l < ndx; ++l) s += jac[i + l * r] * (xn[l] - org[l]);
-        val[i] += s;
-      }
-      for (index_t l = 0; l < nx; ++l) org[l] = xn[l];   // d_difference_dfinish is the identity on a vector space
-    }
+  // ---- outer loop (ddp.hpp:516-523, 576-627, 642-696, 745-842; mat_seq_common.hpp:62-89): the arithmetic runs on the
+  // device (csrc/outer.hip) on the resident derivatives; only the small affine sequences travel -----------------------
+  void download_affine(affine_vector_function_seq_t<scalar_t>& a, int so, int sv, int sj) const {
+    check(ddp_hip_download(ctx, so, a.m_origin.data(), 0, 1), "download origin");
+    if (a.m_val_data.size()) check(ddp_hip_download(ctx, sv, a.m_val_data.data(), 0, 1), "download val");
+    if (a.m_jac_data.size()) check(ddp_hip_download(ctx, sj, a.m_jac_data.data(), 0, 1), "download jac");
   }
-  scalar_t optimality_constr(std::vector<double> const& eq_val) const {
-    scalar_t r = 0; index_t E = 0;
-    for (index_t t = 0; t < T; ++t) {
-      scalar_t s = 0;
-      for (index_t i = 0; i < m_ne[static_cast<size_t>(t)]; ++i) s += eq_val[static_cast<size_t>(E + i)] * eq_val[static_cast<size_t>(E + i)];
-      r = std::max(r, std::sqrt(s));
-      E += m_ne[static_cast<size_t>(t)];
-    }
-    return r;
-  }
-  struct host_derivs { std::vector<double> lfx, lx, lu, fx, fu, eq_val, eq_x, eq_u; };
-  host_derivs fetch(derivative_storage_t const& d) const {
-    return {d.download(DDP_HIP_SEQ_LFX), d.download(DDP_HIP_SEQ_LX), d.download(DDP_HIP_SEQ_LU), d.download(DDP_HIP_SEQ_FX),
-            d.download(DDP_HIP_SEQ_FU), d.download(DDP_HIP_SEQ_EQ_VAL), d.download(DDP_HIP_SEQ_EQ_X), d.download(DDP_HIP_SEQ_EQ_U)};
-  }
-  scalar_t optimality_obj(trajectory_t const& traj, multiplier_seq_t const& mults, scalar_t mu, host_derivs const& h) const {
-    const index_t n = ndx, m = nu;
-    std::vector<scalar_t> adj(h.lfx.begin(), h.lfx.begin() + n), adj2(static_cast<size_t>(n)), pe, lu(static_cast<size_t>(m));
-    scalar_t retval = 0;
-    index_t E = Etot;
-    for (index_t t = T - 1; t >= 0; --t) {
-      const index_t e = m_ne[static_cast<size_t>(t)];
-      E -= e;
-      const double* eqv = h.eq_val.data() + E; const double* eqx = h.eq_x.data() + E * n; const double* equ = h.eq_u.data() + E * m;
-      const double* fx = h.fx.data() + t * n * n; const double* fu = h.fu.data() + t * n * m;
-      const double* x = traj.m_state_data.data() + t * nx;
-      const double* org = mults.m_origin.data() + t * nx;
-      const double* jac = mults.m_jac_data.data() + E * n;
-      pe.assign(static_cast<size_t>(e), 0);
-      for (index_t i = 0; i < e; ++i) {
-        scalar_t s = mults.m_val_data.data()[E + i];
-        for (index_t l = 0; l < n; ++l) s += jac[i + l * e] * (x[l] - org[l]);
-        pe[static_cast<size_t>(i)] = s;
-      }
-      scalar_t nr = 0;
-      for (index_t j = 0; j < m; ++j) {
-        scalar_t s = h.lu[static_cast<size_t>(t * m + j)];
-        for (index_t i = 0; i < e; ++i) s += pe[static_cast<size_t>(i)] * equ[i + j * e] + mu * eqv[i] * equ[i + j * e];
-        for (index_t l = 0; l < n; ++l) s += adj[static_cast<size_t>(l)] * fu[l + j * n];
-        nr += s * s;
-      }
-      retval = std::max(retval, std::sqrt(nr));
-      for (index_t j = 0; j < n; ++j) {
-        scalar_t s = 0;
-        for (index_t l = 0; l < n; ++l) s += adj[static_cast<size_t>(l)] * fx[l + j * n];
-        s += h.lx[static_cast<size_t>(t * n + j)];
-        for (index_t i = 0; i < e; ++i) s += mu * eqv[i] * eqx[i + j * e] + pe[static_cast<size_t>(i)] * eqx[i + j * e] + eqv[i] * jac[i + j * e];
-        adj2[static_cast<size_t>(j)] = s;
-      }
-      adj = adj2;
-    }
-    return retval;
+  struct optimality_t { scalar_t obj, constr; };
+  optimality_t optimality(scalar_t mu) const {
+    double m = mu, o = 0, c = 0;
+    check(ddp_hip_optimality(ctx, &m, &o, &c), "optimality");
+    return {o, c};
   }
 
   template <method M>
@@ -340,39 +283,28 @@ struct ddp_solver_t {   // ddp.hpp:300-869
     ctrl_fb = std::move(bres.feedback);
     for (index_t iter = 0; iter < sp.max_iterations; ++iter) {
       compute_derivatives(derivs, traj);                                 // update_derivatives, :642-696
-      update_origin(mults, traj);
-      update_origin(ctrl_fb, traj);
-      auto h = fetch(derivs);
-      scalar_t opt_obj = optimality_obj(traj, mults, mu, h), opt_constr = optimality_constr(h.eq_val);
+      upload_affine(mults, DDP_HIP_SEQ_MULT_ORIGIN, DDP_HIP_SEQ_MULT_VAL, DDP_HIP_SEQ_MULT_JAC);
+      upload_affine(ctrl_fb, DDP_HIP_SEQ_FB_ORIGIN, DDP_HIP_SEQ_FB_VAL, DDP_HIP_SEQ_FB_JAC);
+      check(ddp_hip_update_origin(ctx, 0), "update_origin(mults)");      // mat_seq_common.hpp:62-89
+      check(ddp_hip_update_origin(ctx, 1), "update_origin(feedback)");
+      auto opt = optimality(mu);                                         // :576-627, :516-523
+      scalar_t opt_obj = opt.obj, opt_constr = opt.constr;
       if (verbose) std::printf("iter %3lld  opt obj %.3e  opt constr %.3e  mu %.3e  reg %.3e  step %.3e\n", (long long)iter, opt_obj, opt_constr, mu, reg, step);
-      if (opt_constr < sp.optimality_stopping_threshold && opt_obj < sp.optimality_stopping_threshold) break;
-      if (opt_obj < w) {
+      const bool done = opt_constr < sp.optimality_stopping_threshold && opt_obj < sp.optimality_stopping_threshold;
+      if (!done && opt_obj < w) {
         if (opt_constr < n) {
-          index_t E = 0;
-          for (index_t t = 0; t < T; ++t) {                              // :680-688
-            const index_t e = m_ne[static_cast<size_t>(t)];
-            const double* eqv = h.eq_val.data() + E; const double* eqx = h.eq_x.data() + E * ndx; const double* equ = h.eq_u.data() + E * nu;
-            const double* k = ctrl_fb.m_val_data.data() + t * nu; const double* K = ctrl_fb.m_jac_data.data() + t * nu * ndx;
-            for (index_t i = 0; i < e; ++i) {
-              scalar_t s = eqv[i];
-              for (index_t l = 0; l < nu; ++l) s += equ[i + l * e] * k[l];
-              mults.m_val_data.data()[E + i] += mu * s;
-            }
-            for (index_t j = 0; j < ndx; ++j)
-              for (index_t i = 0; i < e; ++i) {
-                scalar_t s = eqx[i + j * e];
-                for (index_t l = 0; l < nu; ++l) s += equ[i + l * e] * K[l + j * nu];
-                mults.m_jac_data.data()[E * ndx + i + j * e] += mu * s;
-              }
-            E += e;
-          }
-          scalar_t oo = optimality_obj(traj, mults, mu, h);               // :795-797
+          double m_ = mu;
+          check(ddp_hip_update_multipliers(ctx, &m_), "update_multipliers");   // :680-688
+          scalar_t oo = optimality(mu).obj;                               // :795-797
           n = oo / std::pow(mu, 0.1);
           w /= std::pow(mu, 1.0);
         } else {
           mu *= 10;                                                      // :791
         }
       }
+      download_affine(mults, DDP_HIP_SEQ_MULT_ORIGIN, DDP_HIP_SEQ_MULT_VAL, DDP_HIP_SEQ_MULT_JAC);
+      download_affine(ctrl_fb, DDP_HIP_SEQ_FB_ORIGIN, DDP_HIP_SEQ_FB_VAL, DDP_HIP_SEQ_FB_JAC);
+      if (done) break;
       bres = backward_pass<M>(std::move(ctrl_fb), traj, mults, reg, mu, derivs);   // :804
       mu = bres.mu; reg = bres.reg;
       step = forward_pass<M>(new_traj, traj, mults, bres, true);         // :817

@@ -17,6 +17,9 @@
  *   forward_pass<M>          ddp_fwd.ipp:9-67  (decl ddp.hpp:855)   ddp_hip_forward
  *   cost_seq_aug             ddp.hpp:699-735                        ddp_hip_cost_seq_aug
  *   swap(traj, new_traj)     ddp.hpp:826                            ddp_hip_swap_traj
+ *   update_origin            detail/mat_seq_common.hpp:62-89        ddp_hip_update_origin
+ *   optimality_obj / _constr ddp.hpp:576-627, 516-523               ddp_hip_optimality
+ *   multiplier update        ddp.hpp:680-688 (in update_derivatives) ddp_hip_update_multipliers
  *   (new: multi-seed shard)                           ddp_hip_comm_* / ddp_hip_shard_best
  *
  * Conventions
@@ -159,6 +162,17 @@ int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alpha, double*
 int ddp_hip_cost_seq_aug(ddp_hip_ctx* ctx, int which, const double* mu);
 /* swap(traj, new_traj) (ddp.hpp:826) */
 int ddp_hip_swap_traj(ddp_hip_ctx* ctx);
+
+/* ---- outer augmented-Lagrangian loop (solve<M>, ddp.hpp:745-842): the parts of update_derivatives
+ * (ddp.hpp:642-696) between compute_derivatives and backward_pass, on the resident sequences ---------- */
+/* affine_vector_function_seq_t::update_origin (mat_seq_common.hpp:62-89) with x_new = X:
+ * val += jac (X - origin); origin = X.  which = 0: the multipliers (MULT_*), 1: the control feedback (FB_*) */
+int ddp_hip_update_origin(ddp_hip_ctx* ctx, int which);
+/* optimality_obj (ddp.hpp:576-627) and optimality_constr (ddp.hpp:516-523) of (X, multipliers, derivatives);
+ * mu, obj_out, constr_out: host [batch] */
+int ddp_hip_optimality(ddp_hip_ctx* ctx, const double* mu, double* obj_out, double* constr_out);
+/* p.val += mu (eq + eq_u k), p.jac += mu (eq_x + eq_u K) (ddp.hpp:680-688); mu: host [batch] */
+int ddp_hip_update_multipliers(ddp_hip_ctx* ctx, const double* mu);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 enum ddp_hip_kernel_id {

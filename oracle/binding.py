@@ -277,6 +277,21 @@ class Oracle:
                                       C.byref(ms), C.byref(fs), float(mu))
         return dc, xs_new, us_new
 
+    def update_origin(self, a, rows, xs_new):
+        """affine_vector_function_seq_t::update_origin (mat_seq_common.hpp:62-89), in place on a copy"""
+        a = {k: _f64(v).copy() for k, v in a.items()}
+        st = self._affine_struct(a)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        self.L.orc_update_origin(C.byref(self.p), C.byref(st), rows.ctypes.data_as(_lp), _p(_f64(xs_new)))
+        return a
+
+    def optimality(self, xs, mults, mu, d):
+        ds = self._derivs_struct(d)
+        ms = self._affine_struct(mults)
+        obj = self.L.orc_optimality_obj(C.byref(self.p), _p(_f64(xs)), C.byref(ms), mu, C.byref(ds))
+        constr = self.L.orc_optimality_constr(C.byref(self.p), C.byref(ds))
+        return obj, constr
+
     def solve(self, xs, us, mult_jac_seed, max_iterations, threshold, mu, reg, w, n):
         xs, us = _f64(xs).copy(), _f64(us).copy()
         seed = _f64(mult_jac_seed if len(mult_jac_seed) else np.zeros(1))
