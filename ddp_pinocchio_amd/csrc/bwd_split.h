@@ -119,8 +119,10 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
 // D[row = (l >> 4) + 4 r][col = l & 15].  Rows / columns beyond the matrix are fed zeros.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// ... and, while F = [f_x | f_u] of step td is in LDS, the dense part of that step's Q_x | Q_u: g = F^T V_x
+// (ddp_bwd.ipp:62,67), left in the Q_x | Q_u slots of the instance's workspace for the K4 launch of step td
 template <int N, int M>
-__device__ __forceinline__ void dense_product(const BwdParams& p, int b, int64_t td, double* s_VW, double* s_F) {
+__device__ __forceinline__ void dense_product(const BwdParams& p, int b, int64_t td, double* s_VW, double* s_F, const double* s_vxn) {
   constexpr int n = N, m = M, NM = N + M;
   const int tid = threadIdx.x;
   const int64_t bt = (int64_t)b * p.d.T + td;
@@ -206,6 +208,20 @@ __device__ __forceinline__ void dense_product(const BwdParams& p, int b, int64_t
       else Duu[(jr - n) + (c - n) * m] = acc[r];
     }
   }
+  // g = F^T V_x, one wave per column (two-term partials, then a shuffle tree)
+  double* g = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m);
+  for (int c = wave; c < NM; c += NW) {
+    const double* col = s_F + c * n;
+    double sacc = 0.0;
+    if (lane < n / 2) {
+      const f64x2 a = *reinterpret_cast<const f64x2*>(col + 2 * lane);
+      const f64x2 vv = *reinterpret_cast<const f64x2*>(s_vxn + 2 * lane);
+      sacc = a.x * vv.x + a.y * vv.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+    if (lane == 0) g[c] = sacc;
+  }
 }
 
 // D for the first step to be processed (t = T-1), from V_xx = lfxx (ddp_bwd.ipp:27)
@@ -217,9 +233,11 @@ __global__ __launch_bounds__(BSR) void bwd_dense0(BwdParams p) {
   double* s_VW = smem;
   double* s_F = smem + N * (N + M);
   const double* Vxx = p.ws_V + (int64_t)b * (N + N * N) + N;
+  __shared__ __attribute__((aligned(16))) double s_vxn[N];
   for (int i = threadIdx.x; i < N * N; i += BSR) s_VW[i] = Vxx[i];
+  for (int i = threadIdx.x; i < N; i += BSR) s_vxn[i] = Vxx[i - N];          // V_x = lfx^T (ddp_bwd.ipp:28)
   // (dense_product starts with a barrier after loading F)
-  dense_product<N, M>(p, b, p.d.T - 1, s_VW, s_F);
+  dense_product<N, M>(p, b, p.d.T - 1, s_VW, s_F, s_vxn);
 }
 
 template <int N, int M>
@@ -245,8 +263,6 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   const double* Dxx = D;
   const double* Dux = Dxx + n * n;
   const double* Duu = Dux + m * n;
-  const double* fx = p.fx + bt * n * n;
-  const double* fu = p.fu + bt * n * m;
   const double* eqv = p.eq_val + (int64_t)b * Etot + Eo;
   const double* eqx = p.eq_x + ((int64_t)b * Etot + Eo) * n;
   const double* equ = p.eq_u + ((int64_t)b * Etot + Eo) * m;
@@ -265,8 +281,7 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   double* R = A + lda * M;                     // ldr*NR  [k | K]
   double* S = R + ldr * NR;                    // ldr*N   Q_ux
   double* s_q = S + ldr * N;                   // NM      Q_x | Q_u
-  double* s_vx = s_q + NM;                     // N       incoming V_x
-  double* s_tmp = s_vx + N;                    // emax    pe + mu eq   (ddp_bwd.ipp:46)
+  double* s_tmp = s_q + NM;                    // emax    pe + mu eq   (ddp_bwd.ipp:46)
   static_assert(lda * M + ldr * NR + ldr * N + NM + N + 64 <= N * NM, "phase-A arrays must fit the F region");
 
   // entries of Q in the reference's order of terms (ddp_bwd.ipp:70-87): l, f^T V_xx f, multiplier terms, multiplier
@@ -312,31 +327,21 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     return acc;
   };
 
-  for (int i = tid; i < n; i += BSR) s_vx[i] = Vx[i];
+  __shared__ __attribute__((aligned(16))) double s_vxn[N];   // the new V_x, for the matvec of the next step (dense tail)
   for (int i = tid; i < e; i += BSR) s_tmp[i] = pe[i] + mu * eqv[i];
   __syncthreads();
-  // Q_x, Q_u (:61-68): one wave per column of [f_x | f_u]
-  for (int c = tid >> 6; c < NM; c += BSR >> 6) {
-    const int lane = tid & 63;
-    const double* col = c < n ? fx + c * n : fu + (c - n) * n;
-    double s = 0.0;
-    if (lane < n / 2) {
-      const f64x2 a = *reinterpret_cast<const f64x2*>(col + 2 * lane);
-      const f64x2 vv = *reinterpret_cast<const f64x2*>(s_vx + 2 * lane);
-      s = a.x * vv.x + a.y * vv.y;
+  // Q_x, Q_u (:61-68): the dense part f^T V_x was formed by the previous launch while f was in LDS
+  if (tid < NM) {
+    const int c = tid;
+    const double* g = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m);
+    double acc = c < n ? p.lx[bt * n + c] : p.lu[bt * m + (c - n)];
+    acc += g[c];
+    if (e > 0) {
+      double s1 = 0.0, s2 = 0.0;
+      if (c < n) { for (int k = 0; k < e; ++k) { s1 += eqx[k + c * e] * s_tmp[k]; s2 += pex[k + c * e] * eqv[k]; } acc += s1; acc += s2; }
+      else { for (int k = 0; k < e; ++k) s1 += equ[k + (c - n) * e] * s_tmp[k]; acc += s1; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) {
-      double acc = c < n ? p.lx[bt * n + c] : p.lu[bt * m + (c - n)];
-      acc += s;
-      if (e > 0) {
-        double s1 = 0.0, s2 = 0.0;
-        if (c < n) { for (int k = 0; k < e; ++k) { s1 += eqx[k + c * e] * s_tmp[k]; s2 += pex[k + c * e] * eqv[k]; } acc += s1; acc += s2; }
-        else { for (int k = 0; k < e; ++k) s1 += equ[k + (c - n) * e] * s_tmp[k]; acc += s1; }
-      }
-      s_q[c] = acc;
-    }
+    s_q[c] = acc;
   }
   for (int idx = tid; idx < m * n; idx += BSR) S[idx % m + (idx / m) * ldr] = q_ux(idx % m, idx / m);
   __syncthreads();
@@ -436,6 +441,7 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     for (int l = 0; l < m; ++l) s += S[l + i * ldr] * R[l];
     const double v = s_q[i] + s;
     Vx[i] = v;
+    s_vxn[i] = v;
     if (p.vx_trace) p.vx_trace[bt * n + i] = v;
   }
   for (int idx = tid; idx < n * (n / 4); idx += BSR) {
@@ -466,5 +472,5 @@ __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
     return;
   }
   __syncthreads();   // V_xx complete in LDS; A, R, S, Y are dead: their space becomes F
-  dense_product<N, M>(p, b, t - 1, s_VW, s_F);
+  dense_product<N, M>(p, b, t - 1, s_VW, s_F, s_vxn);
 }
