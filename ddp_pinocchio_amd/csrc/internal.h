@@ -107,7 +107,7 @@ struct ddp_hip_ctx {
   size_t lin_ws_bytes = 0;
   double* lin_qws = nullptr;   // configuration-level workspace of the static path, lin_qws_bt (instance, t) pairs at a time
   int64_t lin_qws_bt = 0;
-  bool lin_static = false;     // the model's tree matches a compiled-in topology (lin_static.hip)
+  int lin_static = 0;          // id of the compiled-in topology the model's tree matches (lin_static.hip), 0 = none
 
   bool profile = false;
   ProfSlot prof[DDP_HIP_K_COUNT];

@@ -806,7 +806,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
     ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * ((d.nv + 1) * d.nv * rbd::QC_STRIDE + (2 * d.nv + 1) * d.nv * rbd::VC_STRIDE));
     HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));
   }
-  ctx->lin_static = want && lin_static_supported(ctx->model_h) && getenv("DDP_HIP_NO_STATIC") == nullptr;
+  ctx->lin_static = (want && getenv("DDP_HIP_NO_STATIC") == nullptr) ? lin_static_supported(ctx->model_h) : 0;
   if (ctx->lin_static) {
     const int64_t BT = ctx->d.batch * ctx->d.T;
     ctx->lin_qws_bt = BT < 1024 ? BT : 1024;

@@ -20,8 +20,8 @@ struct LinParams {
 
 constexpr int LBS = 64;
 
-// static-topology second-order path (lin_static.hip): returns true when the model's tree matches a compiled-in
+// static-topology second-order path (lin_static.hip): returns non-zero when the model's tree matches a compiled-in
 // topology; the launcher covers the velocity- and torque-level stencil points of finite_diff_hessian_compute mode 2
-bool lin_static_supported(const DevModel& m);
+int lin_static_supported(const DevModel& m);   // 0: none, else the id of the compiled-in topology
 void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level);
 int64_t lin_static_ws_per_bt(const DevModel& m);

@@ -38,6 +38,13 @@ struct TopoTalos38 {
                                        0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// UR5-like serial arm (models.cpp:build_chain6; test/pinocchio_ddp.cpp shape): one chain of six revolute joints
+struct TopoChain6 {
+  static constexpr int N = 6;
+  static constexpr int parent[N] = {-1, 0, 1, 2, 3, 4};
+  static constexpr int prismatic[N] = {0, 0, 0, 0, 0, 0};
+};
+
 template <class T> constexpr bool has_child(int k) {
   for (int c = k + 1; c < T::N; ++c) if (T::parent[c] == k) return true;
   return false;
@@ -1333,7 +1340,11 @@ __global__ __launch_bounds__(LBS) void lin_static_vcache_kernel(LinParams p, con
 
 }  // namespace
 
-bool lin_static_supported(const DevModel& m) { return topo_matches<TopoTalos38>(m); }
+int lin_static_supported(const DevModel& m) {
+  if (topo_matches<TopoTalos38>(m)) return 1;
+  if (topo_matches<TopoChain6>(m)) return 2;
+  return 0;
+}
 
 // doubles of workspace one (instance, t) needs at the configuration level
 int64_t lin_static_ws_per_bt(const DevModel& m) {
@@ -1342,8 +1353,8 @@ int64_t lin_static_ws_per_bt(const DevModel& m) {
 }
 
 // level 3: torque-level points (replaces lin_offdiag_kernel<NJ, 3>)
-void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
-  using T = TopoTalos38;
+template <class T>
+static void lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level) {
   const int64_t BT = ctx->d.batch * ctx->d.T;
   constexpr int nv = T::N, TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS;
   if (level == 3) {
@@ -1380,4 +1391,9 @@ void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
     hipLaunchKernelGGL((lin_static_vel_kernel<T, true>), dim3((unsigned)(BT * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_vel_kernel<T, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
   }
+}
+
+void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
+  if (ctx->lin_static == 1) lin_static_launch_t<TopoTalos38>(ctx, p, level);
+  else if (ctx->lin_static == 2) lin_static_launch_t<TopoChain6>(ctx, p, level);
 }

@@ -264,3 +264,12 @@ def test_static_vs_generic_linearisation_full_horizon(gpu, monkeypatch):
             err = float(np.max(np.abs(a - g)))
             tol = 64 * EPS * fscale / (E2 * E2) + 4 * (32 * EPS * fscale / E1) / E2
             assert err <= tol * max(1.0, float(np.max(np.abs(g)))), (k, b, err, tol)
+        # size-independent properties of the stencil: a pair (i, j) is evaluated once and written to both (j, k) orders
+        # (problem.hpp:292-295), so f_xx and f_uu are exactly symmetric in their last two indices at every t
+        n, m = 2 * model.nv, model.nv
+        fxx = out["static"]["fxx", b].reshape(T, n, n, n)       # [t][k][j][i] for element (i, j, k) at i + j n + k n n
+        assert np.array_equal(fxx, fxx.transpose(0, 2, 1, 3))
+        fuu = out["static"]["fuu", b].reshape(T, m, m, n)
+        assert np.array_equal(fuu, fuu.transpose(0, 2, 1, 3))
+        # q+ = q + dt v is linear in x and does not see u: its rows of every tensor carry rounding noise only
+        assert float(np.max(np.abs(out["static"]["fux", b].reshape(T, n, m, n)[..., :model.nv]))) <= tol
