@@ -105,6 +105,7 @@ struct ddp_hip_ctx {
   double* eq_ws = nullptr;     // constraint-chain workspace (large models)
   double* lin_ws = nullptr;
   size_t lin_ws_bytes = 0;
+  int32_t lin_ncfg = 0, lin_nvcfg = 0;   // q- / v-cache entries per (instance, t)
   double* lin_qws = nullptr;   // configuration-level workspace of the static path, lin_qws_bt (instance, t) pairs at a time
   int64_t lin_qws_bt = 0;
   int lin_static = 0;          // id of the compiled-in topology the model's tree matches (lin_static.hip), 0 = none

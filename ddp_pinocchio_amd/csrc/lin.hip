@@ -685,7 +685,8 @@ LinParams make_params(ddp_hip_ctx* ctx) {
     p.eq_c = p.eq_fxk + dd.batch * dd.T * (K > 1 ? K - 1 : 0) * dd.n * dd.n;
   }
   p.qcache = reinterpret_cast<double*>(ctx->lin_ws);
-  p.vcache = p.qcache ? p.qcache + ctx->d.batch * ctx->d.T * (ctx->d.nv + 1) * ctx->d.nv * rbd::QC_STRIDE : nullptr;
+  p.ncfg = ctx->lin_ncfg; p.nvcfg = ctx->lin_nvcfg;
+  p.vcache = p.qcache ? p.qcache + ctx->d.batch * ctx->d.T * (int64_t)ctx->lin_ncfg * ctx->d.nv * rbd::QC_STRIDE : nullptr;
   return p;
 }
 
@@ -717,7 +718,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     prof_begin(ctx, DDP_HIP_K_LIN_FIRST);
     hipLaunchKernelGGL((lin_base_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
     if (ctx->model_h.first_order_fd) {
-      if (ctx->lin_static && fd_mode == 2 && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); lin_static_launch(ctx, p, 0); }
+      if (ctx->lin_static && p.qcache && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); lin_static_launch(ctx, p, 0); }
       else hipLaunchKernelGGL((lin_first_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
     }
     prof_end(ctx, DDP_HIP_K_LIN_FIRST);
@@ -725,7 +726,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
   if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors) {
     prof_begin(ctx, DDP_HIP_K_LIN_SECOND);
     if (fd_mode == 2) {
-      if (p.qcache) {
+      if (p.qcache && p.ncfg > 1) {
         const int nv = (int)d.nv;
         const int64_t TRI = (int64_t)nv * (nv - 1) / 2, Pv = (int64_t)nv * nv + TRI, Pu = 2 * (int64_t)nv * nv + TRI;
         build_caches();
@@ -799,14 +800,18 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
 
 int lin_setup(ddp_hip_ctx* ctx) {
   // q-part cache of the mode-2 stencil (tree models with resident tensors only)
-  const bool want = ctx->model_h.kind == DDP_HIP_MODEL_TREE && ctx->model_h.fd_mode == 2 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS) &&
-                    getenv("DDP_HIP_NO_QCACHE") == nullptr;
-  if (want) {
-    const Dims& d = ctx->d;
-    ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * ((d.nv + 1) * d.nv * rbd::QC_STRIDE + (2 * d.nv + 1) * d.nv * rbd::VC_STRIDE));
+  const bool tree = ctx->model_h.kind == DDP_HIP_MODEL_TREE;
+  const bool tensors = ctx->model_h.fd_mode == 2 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS);
+  const bool want = tree && tensors && getenv("DDP_HIP_NO_QCACHE") == nullptr;
+  const int topo = (tree && getenv("DDP_HIP_NO_STATIC") == nullptr) ? lin_static_supported(ctx->model_h) : 0;
+  const Dims& d = ctx->d;
+  if (want) { ctx->lin_ncfg = (int32_t)d.nv + 1; ctx->lin_nvcfg = 2 * (int32_t)d.nv + 1; }
+  else if (topo && ctx->model_h.first_order_fd) { ctx->lin_ncfg = 1; ctx->lin_nvcfg = 1; }   // first order only: base q, base (q, v)
+  if (ctx->lin_ncfg) {
+    ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * ((int64_t)ctx->lin_ncfg * d.nv * rbd::QC_STRIDE + (int64_t)ctx->lin_nvcfg * d.nv * rbd::VC_STRIDE));
     HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));
+    ctx->lin_static = topo;
   }
-  ctx->lin_static = (want && getenv("DDP_HIP_NO_STATIC") == nullptr) ? lin_static_supported(ctx->model_h) : 0;
   if (ctx->lin_static) {
     const int64_t BT = ctx->d.batch * ctx->d.T;
     ctx->lin_qws_bt = BT < 1024 ? BT : 1024;

@@ -1032,13 +1032,13 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
   const int64_t t = bt % Tn;
   const bool valid = lane < nv;
   const double eps = DIAG ? sqrt(sqrt(DBL_EPSILON)) : sqrt(DBL_EPSILON);
-  const double* __restrict__ qc0 = qcache + (bt * (nv + 1)) * (int64_t)nv * rbd::QC_STRIDE;
+  const double* __restrict__ qc0 = qcache + (bt * p.ncfg) * (int64_t)nv * rbd::QC_STRIDE;
   const double* __restrict__ xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
   const double* __restrict__ ug = us + ((int64_t)b * Tn + t) * nv;
   __shared__ double s_q[(nv + 1) * (nv + 1)];
   double* uq = s_q + (valid ? lane : nv) * (nv + 1);
   if constexpr (LEVEL == 3) {
-    const double* __restrict__ vc = p.vcache + (bt * (2 * nv + 1)) * (int64_t)nv * rbd::VC_STRIDE;
+    const double* __restrict__ vc = p.vcache + (bt * p.nvcfg) * (int64_t)nv * rbd::VC_STRIDE;
     TauState<T> s;
     auto tau = [&](int k) { double v = ug[k]; if (k == lane) v = v + eps; return v; };
     tau_up_all<T, rbd::QC_STRIDE>(*model, qc0, vc, tau, s, std::make_integer_sequence<int, nv>{});
@@ -1274,12 +1274,12 @@ __global__ __launch_bounds__(LBS) void lin_static_qvcache_kernel(LinParams p, co
   const int b = (int)(bt / Tn);
   const int64_t t = bt % Tn;
   __shared__ double s_vel[MAXCH * 6 * LBS];
-  if (lane > nv) return;                         // configurations 0 .. nv (no workgroup barrier below)
+  if (lane >= p.ncfg) return;                    // configurations 0 .. nv, or the base one alone (no workgroup barrier below)
   QvCtx c;
   c.m = model;
   c.xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
-  c.qc = qcache + (bt * (nv + 1) + lane) * (int64_t)nv * rbd::QC_STRIDE;
-  c.vc = vcache + (bt * (2 * nv + 1) + (lane == 0 ? 0 : nv + lane)) * (int64_t)nv * rbd::VC_STRIDE;
+  c.qc = qcache + (bt * p.ncfg + lane) * (int64_t)nv * rbd::QC_STRIDE;
+  c.vc = vcache + (bt * p.nvcfg + (lane == 0 ? 0 : nv + lane)) * (int64_t)nv * rbd::VC_STRIDE;
   c.lvel = s_vel + lane;
   c.jn = lane - 1;
   c.eps = sqrt(sqrt(DBL_EPSILON));
@@ -1362,7 +1362,7 @@ static void lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level)
     hipLaunchKernelGGL((lin_static_tau_kernel<T, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
   } else if (level == 5) {                        // q- and v-caches
     hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
-    hipLaunchKernelGGL((lin_static_vcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
+    if (p.nvcfg > 1) hipLaunchKernelGGL((lin_static_vcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
   } else if (level == 0 || level == 4) {          // 0: first order, 4: diagonal second-order entries
     const int64_t per = ctx->lin_qws_bt * GU;     // one wave per (instance, t) uses one of the GU workspace slots of a slice entry
     for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
