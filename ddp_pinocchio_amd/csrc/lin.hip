@@ -814,7 +814,9 @@ int lin_setup(ddp_hip_ctx* ctx) {
   }
   if (ctx->lin_static) {
     const int64_t BT = ctx->d.batch * ctx->d.T;
-    ctx->lin_qws_bt = BT < 1024 ? BT : 1024;
+    int64_t slice = 1024;
+    if (const char* ev = getenv("DDP_HIP_QWS_BT")) { const int v = atoi(ev); if (v >= 16 && v <= 65536) slice = v; }   // tuning knob
+    ctx->lin_qws_bt = BT < slice ? BT : slice;
     HIP_TRY(hipMalloc(&ctx->lin_qws, sizeof(double) * (size_t)(ctx->lin_qws_bt * lin_static_ws_per_bt(ctx->model_h))));
   }
   // look-ahead states / jacobians of the constraint chain on large models
