@@ -303,8 +303,8 @@ struct RowStage {
   double f0[2 * NV], a1[2 * NV], d1[2 * NV], x[2 * NV];
 };
 
-template <int NV>
-__device__ __forceinline__ void rowblock_stage(RowStage<NV>& S, int lane, const double* __restrict__ f0, const double* __restrict__ a1,
+template <int NV, class ST>
+__device__ __forceinline__ void rowblock_stage(ST& S, int lane, const double* __restrict__ f0, const double* __restrict__ a1,
                                                const double* __restrict__ d1, const double* __restrict__ xg) {
   constexpr int n = 2 * NV;
   for (int k = lane; k < n; k += LBS) { S.f0[k] = f0[k]; S.a1[k] = a1[k]; S.d1[k] = d1[k]; S.x[k] = xg[k]; }
@@ -312,8 +312,8 @@ __device__ __forceinline__ void rowblock_stage(RowStage<NV>& S, int lane, const 
 
 // out: the block [NV][n]; mirror (or null): column c at mirror + c * mstride; a2: contiguous [NV][n]; d2: column c at d2 + c * dstride
 // i: first direction (an x index); jb: x index of the second direction of column 0, or a value >= 2 NV for u directions
-template <int NV>
-__device__ __forceinline__ void rowblock_output(const RowStage<NV>& S, int lane, int i, int jb, double* __restrict__ out,
+template <int NV, class ST>
+__device__ __forceinline__ void rowblock_output(const ST& S, int lane, int i, int jb, double* __restrict__ out,
                                                 double* __restrict__ mirror, int64_t mstride, const double* __restrict__ a2,
                                                 const double* __restrict__ d2, int64_t dstride, double dt) {
   constexpr int n = 2 * NV, TOT = NV * n, UB = 8;
@@ -393,7 +393,10 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   const double* __restrict__ xg = p.x + ((int64_t)b * (Tn + 1) + t) * n;
   const double* __restrict__ ug = p.u + ((int64_t)b * Tn + t) * nv;
   const int iu = i - n, ju = j - n;
-  __shared__ double s_P[ROWS ? nv * PS : 1];
+  // rows: the staged operands are dead once the acceleration pass is over, the output stage's buffers are not alive
+  // before: one LDS region for both (the evaluation and the output stage are a barrier apart)
+  __shared__ union TauLds { double P[ROWS ? nv * PS : 1]; RowStage<nv> S; } s_lds;
+  double* s_P = s_lds.P;
   unsigned int w = warm_block<nv * rbd::VC_STRIDE * 8>(vc, lane);
   if constexpr (ROWS) { stage_placements<nv>(s_P, qc, lane); __syncthreads(); }
   else w ^= warm_block<nv * rbd::QC_STRIDE * 8>(qc, lane);
@@ -413,8 +416,9 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (ROWS) {
-    __shared__ RowStage<nv> S;
+    RowStage<nv>& S = s_lds.S;
     const int mm = nv;
+    __syncthreads();                       // every lane is done with the staged operands
     // unconditional on purpose: under `if (valid)` the optimiser sinks the whole evaluation into the branch, away from
     // its operand loads, and every operand then spills
     const int row = valid ? lane : nv;
