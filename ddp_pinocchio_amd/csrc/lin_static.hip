@@ -460,11 +460,13 @@ template <class T>
 struct VelState {
   double vel[T::N][6];   // link velocities (a chain at a time, plus the branching joints)
   double acc[T::N][6];   // bias-force accumulators, then link accelerations
+  double uu[T::N];       // u_i, then the joint acceleration (contexts with UQS == 0; else they live in LDS behind uq)
 };
 
 template <int UQS_, int QS_ = rbd::QC_STRIDE>
 struct VelCtx {
-  static constexpr int UQS = UQS_;   // stride between consecutive joints of this lane's u_i / acceleration buffer
+  static constexpr int UQS = UQS_;   // stride between consecutive joints of this lane's u_i / acceleration buffer in LDS;
+                                     // 0: no buffer, the values stay in registers (VelState::uu)
   static constexpr int QS = QS_;     // doubles per joint of the (E | r | U | 1/D) block behind qp
   const DevModel* m;
   const double* qp;                  // (E | r | U | 1/D): the q-cache block itself, or its copy in LDS
@@ -547,7 +549,7 @@ __device__ __forceinline__ void chain_up(const C& c, VelState<T>& s) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) sp += a[k] * pAi[o + k];
   const double ui = c.ug[K] - sp;
-  c.uq[K * C::UQS] = ui;
+  if constexpr (C::UQS == 0) s.uu[K] = ui; else c.uq[K * C::UQS] = ui;
   constexpr int par = T::parent[K];
   if constexpr (par >= 0) {
     const double vK = lane_v<T::N>(c, K);
@@ -618,8 +620,10 @@ __device__ __forceinline__ void vel_down(const C& c, VelState<T>& s) {
   double sum = 0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; sum += U[k] * ap[k]; }
-  const double qd = (c.uq[K * C::UQS] - sum) * dinv;
-  c.uq[K * C::UQS] = qd;
+  double ui;
+  if constexpr (C::UQS == 0) ui = s.uu[K]; else ui = c.uq[K * C::UQS];
+  const double qd = (ui - sum) * dinv;
+  if constexpr (C::UQS == 0) s.uu[K] = qd; else c.uq[K * C::UQS] = qd;
   if constexpr (has_child<T>(K)) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) { s.vel[K][k] = vel[k]; s.acc[K][k] = ap[k]; }
@@ -636,7 +640,7 @@ __device__ __forceinline__ void vel_down_all(const C& c, VelState<T>& s, std::in
 //   ROWS:  g < nv : (q_g, v_lane)      cfg 1+g   38 of 64 lanes, row-block output (+ mirror image)
 //   !ROWS: (v_i, v_j) pairs, cfg 0, 64 pairs per wave, generic output
 template <class T, bool ROWS>
-__global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
+__global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinParams p) {
   constexpr int nv = T::N, n = 2 * nv;
   constexpr int TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS, G = ROWS ? nv : GU;
   const int64_t bt = blockIdx.x / G;
@@ -654,10 +658,13 @@ __global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
     tri_index(valid ? pid : 0, nv, i, j);
     i += nv; j += nv; cfg = 0;
   }
+  // rows: u_i / the accelerations stay in registers, and the staged operands (dead after the acceleration pass) share
+  // their LDS with the output stage's buffers (alive after it)
   using Stage = typename std::conditional<ROWS, RowStage<nv>, OutStage<nv>>::type;
-  __shared__ Stage S;
-  VelCtx<ROWS ? 1 : LBS, ROWS ? PS : rbd::QC_STRIDE> c;
-  __shared__ double s_P[ROWS ? nv * PS : 1];
+  __shared__ union VelLds { Stage S; double P[ROWS ? nv * PS : 1]; } s_lds;
+  Stage& S = s_lds.S;
+  double* s_P = s_lds.P;
+  VelCtx<ROWS ? 0 : LBS, ROWS ? PS : rbd::QC_STRIDE> c;
   c.m = p.model;
   c.qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
   c.qp = ROWS ? s_P : c.qc;
@@ -665,9 +672,8 @@ __global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
   c.ug = p.u + ((int64_t)b * Tn + t) * nv;
   c.i = i; c.j = j;
   c.eps = sqrt(sqrt(DBL_EPSILON));
-  // rows: lane-major with an odd stride (the layout the row-block output reads), idle lanes share the spare row;
   // pairs: joint-major ([joint][lane]) for the generic output stage
-  if constexpr (ROWS) c.uq = S.q + (valid ? lane : nv) * (nv + 1);
+  if constexpr (ROWS) c.uq = nullptr;
   else c.uq = &S.qdd[0][lane];
   const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
   if (w == 0x7fc01234u) c.eps = 0.0;     // never true in practice; orders the evaluation behind the warm-up
@@ -682,6 +688,12 @@ __global__ __launch_bounds__(LBS) void lin_static_vel_kernel(LinParams p) {
   if constexpr (ROWS) {
     double* fxx = kp->fxx + bt * n * n * n;
     const double* fxb = kp->fx + bt * n * n;
+    __syncthreads();                       // every lane is done with the staged operands
+    // lane-major with an odd stride (the layout the row-block output reads), idle lanes share the spare row; unconditional
+    // stores right behind the evaluation (see the torque-level kernel)
+    const int row = valid ? lane : nv;
+#pragma unroll
+    for (int k = 0; k < nv; ++k) S.q[row * (nv + 1) + k] = s.uu[k];
     rowblock_stage<nv>(S, lane, kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
     __syncthreads();
     // column (k, v_c) of slab q_i of f_xx: k + (nv + c) n + i n n; its mirror image: column q_i of slab v_c
