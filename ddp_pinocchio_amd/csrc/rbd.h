@@ -688,12 +688,26 @@ __device__ void aba_tree_coop(const DevModel& m, const double* q, const double* 
   auto S = [&](int joint, int slot) -> double& { return st[(joint * ABA_LDS_SLOTS + slot) * TPB + cand]; };
   constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oI = 24, oU = 45, oD = 51, oT = 52, oV = 53;
   const int NL = m.n_levels;
+  // joint placements depend on q alone: all joints at once, off the level-by-level critical path
+  if (live)
+    for (int i = h; i < m.nv; i += NH) {
+      double E[9], R[3];
+      joint_placement(m, i, q[i], E, R);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S(i, oE + k) = E[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) S(i, oR + k) = R[k];
+    }
+  __syncthreads();
   for (int L = 0; L < NL; ++L) {                 // pass 1, root -> leaves
     const int idx = m.lvl_start[L] + h;
     if (live && idx < m.lvl_start[L + 1]) {
       const int i = m.lvl_joint[idx];
       double E[9], R[3], vel[6], vp[6], cb[6], pA[6], Iv[6], I6[21];
-      joint_placement(m, i, q[i], E, R);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
       const double* a = m.axis[i];
       double vJ[6] = {0, 0, 0, 0, 0, 0};
       const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
@@ -714,10 +728,6 @@ __device__ void aba_tree_coop(const DevModel& m, const double* q, const double* 
       for (int k = 0; k < 21; ++k) I6[k] = m.I6[i][k];
       sym6_mv(I6, vel, Iv);
       crf(vel, Iv, pA);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) S(i, oE + k) = E[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) S(i, oR + k) = R[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) { S(i, oV + k) = vel[k]; S(i, oC + k) = cb[k]; S(i, oP + k) = pA[k]; }
 #pragma unroll
