@@ -192,3 +192,46 @@ def test_shard_best_single_rank_rccl(gpu):
     assert L.ddp_hip_shard_best(comm, -2.5, 17, C.byref(cost), C.byref(idx)) == 0
     assert cost.value == -2.5 and idx.value == 17
     assert L.ddp_hip_comm_destroy(comm) == 0
+
+
+@pytest.mark.gpu
+def test_two_contexts_from_two_host_threads(gpu):
+    """include/ddp_hip/ddp_hip.h: contexts are independent and may be driven from different host threads (one context =
+    one HIP stream).  Two contexts running a full iteration concurrently give bit for bit what each gives alone."""
+    import threading
+    from problems import initial_trajectory, make
+    capi = gpu
+    T, B = 6, 2
+    model, spec, o = make("tree38", T, batch=B, fd_mode=2)
+
+    def setup(seed):
+        ctx = capi.Context(spec)
+        for b in range(B):
+            x0, us, xs = initial_trajectory(o, model, seed=seed + b, u_sigma=0.3)
+            ctx.upload("X", xs, b, 1); ctx.upload("U", us, b, 1)
+            ctx.upload("X_NEW", xs, b, 1); ctx.upload("U_NEW", us, b, 1)
+        return ctx
+
+    def iterate(ctx, out, key):
+        ctx.linearize()
+        rc, reg, mu, restarts = ctx.backward(0.0, 1.0)
+        rc2, step, dcost = ctx.forward(mu, n_alpha=8)
+        out[key] = (ctx.download("FB_JAC"), ctx.download("X_NEW"), step.copy(), reg.copy())
+
+    alone, together = {}, {}
+    for k, seed in (("a", 100), ("b", 200)):
+        with setup(seed) as ctx:
+            iterate(ctx, alone, k)
+    ca, cb = setup(100), setup(200)
+    try:
+        th = [threading.Thread(target=iterate, args=(ca, together, "a")), threading.Thread(target=iterate, args=(cb, together, "b"))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    finally:
+        ca.close(); cb.close()
+    for k in ("a", "b"):
+        assert k in together, "a worker thread failed"
+        for x, y in zip(alone[k], together[k]):
+            assert np.array_equal(x, y)
