@@ -227,6 +227,41 @@ def test_forward_line_search_floor(gpu):
 
 
 @pytest.mark.gpu
+def test_static_vs_generic_linearisation_chain6(gpu, monkeypatch):
+    """The second compiled-in topology (UR5-like chain, BASELINE config 2 horizon T = 100): static vs run-time-tree
+    stencil kernels on the same trajectories, constraint stage included."""
+    capi = gpu
+    T, B = 100, 4
+    model, spec, o = make("chain6", T, batch=B, fd_mode=2)
+    rng = np.random.default_rng(9)
+    us = 0.05 * rng.normal(size=(B, T * model.nv))
+    out = {}
+    seqs = ("F_VAL", "FX", "FU", "FXX", "FUX", "FUU", "EQ_VAL", "EQ_X", "EQ_U", "EQ_XX")
+    for tag in ("static", "generic"):
+        if tag == "generic":
+            monkeypatch.setenv("DDP_HIP_NO_STATIC", "1")
+        with capi.Context(spec) as ctx:
+            ctx.upload("X", np.zeros((B, (T + 1) * 2 * model.nv)))
+            ctx.upload("U", us)
+            ctx.rollout()
+            ctx.linearize()
+            out[tag] = {s: ctx.download(s) for s in seqs}
+    monkeypatch.delenv("DDP_HIP_NO_STATIC")
+    EPS, E1, E2 = 2.220446049250313e-16, 1.4901161193847656e-08, 1.220703125e-04
+    fscale = max(1.0, float(np.max(np.abs(out["generic"]["F_VAL"]))))
+    assert np.array_equal(out["static"]["F_VAL"], out["generic"]["F_VAL"])
+    tol1 = 32 * EPS * fscale / E1
+    tol2 = 64 * EPS * fscale / (E2 * E2) + 4 * tol1 / E2
+    for s in seqs[1:]:
+        a, g = out["static"][s], out["generic"][s]
+        tol = tol1 if s in ("FX", "FU", "EQ_VAL", "EQ_X", "EQ_U") else tol2
+        if s.startswith("EQ"):
+            tol *= 8
+        assert np.all(np.isfinite(a)), s
+        assert float(np.max(np.abs(a - g))) <= tol * max(1.0, float(np.max(np.abs(g)))), (s, float(np.max(np.abs(a - g))), tol)
+
+
+@pytest.mark.gpu
 def test_static_vs_generic_linearisation_full_horizon(gpu, monkeypatch):
     """The static-topology stencil kernels (lin_static.hip) against the generic run-time-tree kernels (lin.hip) at the
     full horizon, with more (instance, t) pairs than one workspace slice holds (1 024): same stencil, same caches, the
