@@ -82,15 +82,28 @@ def _abs_err(ctx, d, key, seq):
     ("tree38_frame", 4, 2), ("tree38_frame", 5, 0), ("tree38_config", 3, 2),
 ])
 def test_linearize_parity(gpu, name, T, fd_mode):
+    _linearize_parity(gpu, name, T, fd_mode, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_seed", [7, 12345])
+def test_linearize_parity_other_tree_seeds(gpu, model_seed):
+    """the compiled-in topology fixes the tree, not its numbers: other seeded masses / placements / inertias"""
+    # (the bound is stated in ulps of f; on some seeded models the intermediates of the ABA are larger than f, and the
+    # device and the oracle -- run-time-tree kernels included -- sit 9-10 ulp apart instead of < 8)
+    _linearize_parity(gpu, "tree38", 3, 2, model_seed, ulps=16)
+
+
+def _linearize_parity(gpu, name, T, fd_mode, model_seed, ulps=8):
     capi = gpu
-    model, spec, o = make(name, T, fd_mode=fd_mode)
+    model, spec, o = make(name, T, fd_mode=fd_mode, seed=model_seed)
     x0, us, xs = initial_trajectory(o, model, seed=3, u_sigma=0.05 if name.startswith("chain6") else 0.5)
     d = o.compute_derivatives(xs, us)
     # FD noise bounds (module docstring), scaled by the magnitude of f
     EPS, E1, E2 = 2.220446049250313e-16, 1.4901161193847656e-08, 1.220703125e-04
     fscale = max(1.0, float(np.max(np.abs(d["f_val"]))))
-    tol_first = 8 * EPS * fscale / E1
-    tol_second_iso = 64 * EPS * fscale / (E2 * E2)
+    tol_first = ulps * EPS * fscale / E1
+    tol_second_iso = 8 * ulps * EPS * fscale / (E2 * E2)
     tol_second_e2e = tol_second_iso + 4 * tol_first / E2
     with capi.Context(spec) as ctx:
         _upload_traj(ctx, xs, us)
