@@ -732,12 +732,13 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         build_caches();
         if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_DIAG") == nullptr) lin_static_launch(ctx, p, 4);
         else hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
-        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CFG") == nullptr) lin_static_launch(ctx, p, 1);
-        else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
-        if (ctx->lin_static) lin_static_launch(ctx, p, 2);
-        else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
+        // torque level first: on the static path its row kernel also forms the diagonal entries of the q and v directions
         if (ctx->lin_static) lin_static_launch(ctx, p, 3);
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 3>), dim3(blocks_for(BT * Pu)), dim3(LBS), 0, ctx->stream, p);
+        if (ctx->lin_static) lin_static_launch(ctx, p, 2);
+        else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
+        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CFG") == nullptr) lin_static_launch(ctx, p, 1);
+        else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
       } else {
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 0>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p);

@@ -299,15 +299,48 @@ __device__ __forceinline__ void offdiag_output(const LinParams& p, OutStage<NV>&
 // staged in LDS once; the accelerations are left in LDS lane-major with an odd row stride (conflict free both ways).
 template <int NV>
 struct RowStage {
-  double q[(NV + 1) * (NV + 1)];   // one extra row: where the idle lanes of the wave leave their values
+  // rows 0 .. NV-1: the row's points; row NV: the torque-level kernel's extra point (direction i alone, see
+  // rowblock_stage); row NV+1: where the idle lanes of the wave leave their values
+  double q[(NV + 2) * (NV + 1)];
   double f0[2 * NV], a1[2 * NV], d1[2 * NV], x[2 * NV];
 };
 
-template <int NV, class ST>
+// DIAG_ROW = false: the diagonal second-order column (i, i) is read from d1.  DIAG_ROW = true (torque-level rows): lane
+// NV of the wave has evaluated the point "direction i alone" on the same cached operands (an otherwise idle lane); the
+// column (problem.hpp:192-222: 2 ((f(x + eps e_i) - f(x)) - eps f_col_i) / eps^2) is formed here, kept for the row's
+// own off-diagonal entries and written to d1 for the velocity- and configuration-level kernels that follow.
+template <int NV, bool DIAG_ROW, class ST>
 __device__ __forceinline__ void rowblock_stage(ST& S, int lane, const double* __restrict__ f0, const double* __restrict__ a1,
-                                               const double* __restrict__ d1, const double* __restrict__ xg) {
+                                               double* __restrict__ d1, const double* __restrict__ xg, int i = 0, double dt = 0.0) {
   constexpr int n = 2 * NV;
-  for (int k = lane; k < n; k += LBS) { S.f0[k] = f0[k]; S.a1[k] = a1[k]; S.d1[k] = d1[k]; S.x[k] = xg[k]; }
+  if constexpr (DIAG_ROW) {
+    __syncthreads();     // row NV of q is another lane's
+    const double eps = sqrt(sqrt(DBL_EPSILON));
+    const double eps2 = eps * eps;
+    for (int k = lane; k < n; k += LBS) {
+      const double f0k = f0[k], a1k = a1[k];
+      double xk = xg[k];
+      S.x[k] = xk;
+      if (k == i) xk = xk + eps;
+      double fv;
+      if (k < NV) {
+        double xv = xg[NV + k];
+        if (NV + k == i) xv = xv + eps;
+        const double vo = dt * xv;
+        fv = xk + vo;
+      } else {
+        fv = xk + S.q[NV * (NV + 1) + (k - NV)] * dt;
+      }
+      double df = fv - f0k;
+      df -= eps * a1k;
+      df *= 2;
+      const double dd = df / eps2;
+      S.f0[k] = f0k; S.a1[k] = a1k; S.d1[k] = dd;
+      d1[k] = dd;
+    }
+  } else {
+    for (int k = lane; k < n; k += LBS) { S.f0[k] = f0[k]; S.a1[k] = a1[k]; S.d1[k] = d1[k]; S.x[k] = xg[k]; }
+  }
 }
 
 // out: the block [NV][n]; mirror (or null): column c at mirror + c * mstride; a2: contiguous [NV][n]; d2: column c at d2 + c * dstride
@@ -421,11 +454,11 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
     __syncthreads();                       // every lane is done with the staged operands
     // unconditional on purpose: under `if (valid)` the optimiser sinks the whole evaluation into the branch, away from
     // its operand loads, and every operand then spills
-    const int row = valid ? lane : nv;
+    const int row = lane <= nv ? lane : nv + 1;      // lane nv: direction i alone (its second direction index falls off the controls)
 #pragma unroll
     for (int k = 0; k < nv; ++k) S.q[row * (nv + 1) + k] = s.uu[k];
     // (the staging loop comes after these stores: the evaluation must meet its first use in its own basic block)
-    rowblock_stage<nv>(S, lane, kp->f_val + bt * n, kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg);
+    rowblock_stage<nv, true>(S, lane, kp->f_val + bt * n, kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg, i, m.dt);
     __syncthreads();
     // column (k, u_c) of the (x_i, u) slab of f_ux: k + c n + i n m
     rowblock_output<nv>(S, lane, i, n, kp->fux + bt * n * mm * n + (int64_t)i * n * mm, nullptr, 0, kp->fu + bt * n * mm,
@@ -694,7 +727,7 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
     const int row = valid ? lane : nv;
 #pragma unroll
     for (int k = 0; k < nv; ++k) S.q[row * (nv + 1) + k] = s.uu[k];
-    rowblock_stage<nv>(S, lane, kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
+    rowblock_stage<nv, false>(S, lane, kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
     __syncthreads();
     // column (k, v_c) of slab q_i of f_xx: k + (nv + c) n + i n n; its mirror image: column q_i of slab v_c
     rowblock_output<nv>(S, lane, i, nv, fxx + (int64_t)nv * n + (int64_t)i * n * n, fxx + (int64_t)i * n + (int64_t)nv * n * n, (int64_t)n * n,
@@ -1379,20 +1412,18 @@ static void lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level)
   } else if (level == 5) {                        // q- and v-caches
     hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
     if (p.nvcfg > 1) hipLaunchKernelGGL((lin_static_vcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
-  } else if (level == 0 || level == 4) {          // 0: first order, 4: diagonal second-order entries
+  } else if (level == 0) {                        // first order
     const int64_t per = ctx->lin_qws_bt * GU;     // one wave per (instance, t) uses one of the GU workspace slots of a slice entry
     for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
       const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
-      if (level == 0) hipLaunchKernelGGL((lin_static_first_kernel<T, 1, false>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
-      else hipLaunchKernelGGL((lin_static_first_kernel<T, 1, true>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
+      hipLaunchKernelGGL((lin_static_first_kernel<T, 1, false>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
     }
-    if (level == 0) {
-      hipLaunchKernelGGL((lin_static_first_kernel<T, 2, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
-      hipLaunchKernelGGL((lin_static_first_kernel<T, 3, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
-    } else {
-      hipLaunchKernelGGL((lin_static_first_kernel<T, 2, true>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
-      hipLaunchKernelGGL((lin_static_first_kernel<T, 3, true>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
-    }
+    hipLaunchKernelGGL((lin_static_first_kernel<T, 2, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+    hipLaunchKernelGGL((lin_static_first_kernel<T, 3, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+  } else if (level == 4) {
+    // diagonal second-order entries of the u directions; those of the q and v directions are formed by the torque-level
+    // row kernel (level 3) on an otherwise idle lane, which therefore runs ahead of levels 2 and 1
+    hipLaunchKernelGGL((lin_static_first_kernel<T, 3, true>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
   } else if (level == 1) {
     // in slices of (instance, t), so that the per-wave workspace stays small
     const int64_t per = ctx->lin_qws_bt;
