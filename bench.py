@@ -37,6 +37,8 @@ def parse():
                     help="full = with second-order tensors (the reference's algorithm); gn = tensor-free variant")
     ap.add_argument("--n-alpha", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="development: do not bracket the kernel launches with HIP events (no roofline / per-kernel times)")
     ap.add_argument("--cpu-sample-steps", type=int, default=0, help="horizon of the CPU sample (0 = auto)")
     return ap.parse_args()
 
@@ -112,7 +114,12 @@ def main():
     for _ in range(a.warmup):
         one_iteration(False)
 
-    ctx.profile_enable(True)
+    # HIP events around every launch of the roofline kernel (K3) and of the few-launch kernels; K4's 200 launches per sweep
+    # are left out (an event pair costs stream time): its figure below is the backward phase minus K3
+    if a.no_kernel_events:
+        ctx.profile_enable(False)
+    else:
+        ctx.profile_enable(True, kernels=[capi.K_BWD_ASSEMBLE, capi.K_FWD_ROLLOUT, capi.K_LIN_FIRST, capi.K_LIN_SECOND])
     ctx.profile_reset()
     if world > 1:
         dist.barrier()
@@ -160,7 +167,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(S),
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": n_a},
             "phases_ms_per_step": {k: v / a.steps for k, v in phase_ms.items()},
-            "kernels_ms_per_step": {"bwd_contract": ms_a / a.steps, "bwd_riccati": ms_g / a.steps, "fwd_rollout": ms_f / a.steps,
+            "kernels_ms_per_step": {"bwd_contract": ms_a / a.steps,
+                                    "bwd_riccati_and_gaps": (phase_ms["backward"] - ms_a) / a.steps, "fwd_rollout": ms_f / a.steps,
                                     "lin_first": ms_l1 / a.steps, "lin_second": ms_l2 / a.steps},
         }
         if not a.no_cpu_baseline:

@@ -299,8 +299,10 @@ class Context:
         mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
         _check(lib().ddp_hip_update_multipliers(self._h, _ptr(mu)), "update_multipliers")
 
-    def profile_enable(self, on=True):
-        _check(lib().ddp_hip_profile_enable(self._h, 1 if on else 0), "profile_enable")
+    def profile_enable(self, on=True, kernels=None):
+        """on: every kernel class; kernels: an iterable of K_* ids to bracket only those"""
+        mask = (1 if on else 0) if kernels is None else sum(2 << k for k in kernels)
+        _check(lib().ddp_hip_profile_enable(self._h, mask), "profile_enable")
 
     def profile_reset(self):
         _check(lib().ddp_hip_profile_reset(self._h), "profile_reset")

@@ -376,7 +376,7 @@ extern "C" int ddp_hip_swap_traj(ddp_hip_ctx* ctx) {
 
 // ---- profiling: HIP events on the context's own stream around every launch of a kernel class --
 void prof_begin(ddp_hip_ctx* ctx, int kid) {
-  if (!ctx->profile) return;
+  if (!(ctx->profile_mask & (2u << kid))) return;
   ProfSlot& p = ctx->prof[kid];
   if (p.used == p.starts.size()) {
     hipEvent_t a, b;
@@ -387,7 +387,7 @@ void prof_begin(ddp_hip_ctx* ctx, int kid) {
   (void)hipEventRecord(p.starts[p.used], ctx->stream);
 }
 void prof_end(ddp_hip_ctx* ctx, int kid) {
-  if (!ctx->profile) return;
+  if (!(ctx->profile_mask & (2u << kid))) return;
   ProfSlot& p = ctx->prof[kid];
   if (p.used >= p.stops.size()) return;
   (void)hipEventRecord(p.stops[p.used], ctx->stream);
@@ -408,8 +408,8 @@ static void prof_collect(ddp_hip_ctx* ctx) {
 
 extern "C" int ddp_hip_profile_enable(ddp_hip_ctx* ctx, int on) {
   if (!ctx) return DDP_HIP_E_ARG;
-  if (ctx->profile && !on) prof_collect(ctx);
-  ctx->profile = on != 0;
+  if (ctx->profile_mask && !on) prof_collect(ctx);
+  ctx->profile_mask = on == 1 ? ~0u : (uint32_t)on;      // 1: every class; else bit (1 + kernel_id) selects a class
   return DDP_HIP_OK;
 }
 extern "C" int ddp_hip_profile_reset(ddp_hip_ctx* ctx) {

@@ -110,7 +110,7 @@ struct ddp_hip_ctx {
   int64_t lin_qws_bt = 0;
   int lin_static = 0;          // id of the compiled-in topology the model's tree matches (lin_static.hip), 0 = none
 
-  bool profile = false;
+  uint32_t profile_mask = 0;   // bit (1 + kernel_id): that kernel class is bracketed by HIP events
   ProfSlot prof[DDP_HIP_K_COUNT];
 };
 

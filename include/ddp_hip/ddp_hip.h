@@ -183,7 +183,9 @@ enum ddp_hip_kernel_id {
   DDP_HIP_K_LIN_SECOND,
   DDP_HIP_K_COUNT
 };
-/* when enabled, HIP events bracket every launch of every kernel class on the context's stream */
+/* when enabled, HIP events bracket every launch of the selected kernel classes on the context's stream.
+ * on: 0 off; 1 every class; otherwise a bit mask, bit (1 + kernel_id) selects class kernel_id (an event pair costs
+ * a few microseconds of stream time per launch: K4's 200 launches per sweep are worth leaving out of a timed run) */
 int ddp_hip_profile_enable(ddp_hip_ctx* ctx, int on);
 int ddp_hip_profile_reset(ddp_hip_ctx* ctx);
 int ddp_hip_profile_get(ddp_hip_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
