@@ -108,6 +108,9 @@ struct ddp_hip_ctx {
   int32_t lin_ncfg = 0, lin_nvcfg = 0;   // q- / v-cache entries per (instance, t)
   double* lin_qws = nullptr;   // configuration-level workspace of the static path, lin_qws_bt (instance, t) pairs at a time
   int64_t lin_qws_bt = 0;
+  double* lin_qws2 = nullptr;  // second workspace + stream + events: the two configuration-level kernels of consecutive slices overlap
+  hipStream_t lin_stream2 = nullptr;
+  hipEvent_t lin_ev_up[2] = {nullptr, nullptr}, lin_ev_dn[2] = {nullptr, nullptr};
   int lin_static = 0;          // id of the compiled-in topology the model's tree matches (lin_static.hip), 0 = none
 
   uint32_t profile_mask = 0;   // bit (1 + kernel_id): that kernel class is bracketed by HIP events

@@ -819,6 +819,14 @@ int lin_setup(ddp_hip_ctx* ctx) {
     if (const char* ev = getenv("DDP_HIP_QWS_BT")) { const int v = atoi(ev); if (v >= 16 && v <= 65536) slice = v; }   // tuning knob
     ctx->lin_qws_bt = BT < slice ? BT : slice;
     HIP_TRY(hipMalloc(&ctx->lin_qws, sizeof(double) * (size_t)(ctx->lin_qws_bt * lin_static_ws_per_bt(ctx->model_h))));
+    if (ctx->lin_ncfg > 1) {     // the mode-2 stencil is resident: its configuration level runs slice-pipelined on two streams
+      HIP_TRY(hipMalloc(&ctx->lin_qws2, sizeof(double) * (size_t)(ctx->lin_qws_bt * lin_static_ws_per_bt(ctx->model_h))));
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->lin_stream2, hipStreamNonBlocking));
+      for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&ctx->lin_ev_up[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->lin_ev_dn[k], hipEventDisableTiming));
+      }
+    }
   }
   // look-ahead states / jacobians of the constraint chain on large models
   if (ctx->d.Etot > 0 && ctx->d.nv > 6) {
@@ -830,6 +838,12 @@ int lin_setup(ddp_hip_ctx* ctx) {
   return DDP_HIP_OK;
 }
 void lin_teardown(ddp_hip_ctx* ctx) {
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->lin_ev_up[k]) (void)hipEventDestroy(ctx->lin_ev_up[k]);
+    if (ctx->lin_ev_dn[k]) (void)hipEventDestroy(ctx->lin_ev_dn[k]);
+  }
+  if (ctx->lin_stream2) (void)hipStreamDestroy(ctx->lin_stream2);
+  if (ctx->lin_qws2) (void)hipFree(ctx->lin_qws2);
   if (ctx->lin_qws) (void)hipFree(ctx->lin_qws);
   if (ctx->eq_ws) (void)hipFree(ctx->eq_ws);
   if (ctx->lin_ws) (void)hipFree(ctx->lin_ws);

@@ -1425,15 +1425,25 @@ static void lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level)
     // row kernel (level 3) on an otherwise idle lane, which therefore runs ahead of levels 2 and 1
     hipLaunchKernelGGL((lin_static_first_kernel<T, 3, true>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
   } else if (level == 1) {
-    // in slices of (instance, t), so that the per-wave workspace stays small
+    // In slices of (instance, t), so that the per-wave workspace stays small.  The sweep kernel of slice k+1 (one wave per
+    // SIMD, long waves) and the acceleration / output kernel of slice k run on two streams with two workspaces: each
+    // fills the other's tail instead of leaving the chip to drain between launches.
     const int64_t per = ctx->lin_qws_bt;
-    for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
+    hipStream_t s0 = ctx->stream, s1 = ctx->lin_stream2;
+    int k = 0;
+    for (int64_t bt0 = 0; bt0 < BT; bt0 += per, ++k) {
       const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
-      hipLaunchKernelGGL((lin_static_cfg_up_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u,
-                         ctx->lin_qws, bt0);
-      hipLaunchKernelGGL((lin_static_cfg_down_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u,
-                         ctx->lin_qws, bt0);
+      const int w = k & 1;
+      double* ws = w ? ctx->lin_qws2 : ctx->lin_qws;
+      if (k >= 2) (void)hipStreamWaitEvent(s0, ctx->lin_ev_dn[w], 0);           // slice k-2 is done with this workspace
+      hipLaunchKernelGGL((lin_static_cfg_up_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, s0, p, p.model, p.qcache, p.x, p.u, ws, bt0);
+      (void)hipEventRecord(ctx->lin_ev_up[w], s0);
+      (void)hipStreamWaitEvent(s1, ctx->lin_ev_up[w], 0);
+      hipLaunchKernelGGL((lin_static_cfg_down_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, s1, p, p.model, p.qcache, p.x, p.u, ws, bt0);
+      (void)hipEventRecord(ctx->lin_ev_dn[w], s1);
     }
+    if (k >= 1) (void)hipStreamWaitEvent(s0, ctx->lin_ev_dn[0], 0);
+    if (k >= 2) (void)hipStreamWaitEvent(s0, ctx->lin_ev_dn[1], 0);
   } else if (level == 2) {
     hipLaunchKernelGGL((lin_static_vel_kernel<T, true>), dim3((unsigned)(BT * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_vel_kernel<T, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
