@@ -2,11 +2,17 @@
 """bench.py -- DDP iterations/s on the Talos-like 38-DoF tree, horizon T = 200 (BASELINE.json metric).
 
 One "step" = one full DDP iteration of every resident instance on this GPU:
-    linearise (FD f_x, f_u + FD second-order tensors, mode 2)  ->  backward sweep (with tensors)
+    linearise (first-order jacobians + second-order tensors)  ->  backward sweep (with tensors)
     ->  forward sweep with 8 batched line-search steps  ->  swap trajectories (+ the reg rule of ddp.hpp:819-824)
-with all inputs resident in HBM.  Independent instances (random control seeds) are sharded across
-ranks with no data-path collective (weak scaling: `--seeds-per-gpu` instances per GPU); the only exchange
-is the best-cost pick: one RCCL all-reduce(min) of 8 bytes + one of the masked index per step.
+with all inputs resident in HBM.  Independent instances (random control seeds) are sharded across ranks with no
+data-path collective; the only exchange is the best-cost pick: two 8-byte RCCL all-reduces per step through the
+library's own ddp_hip_shard_best (csrc/comm.cpp).
+
+Workloads (BASELINE.json configs):
+    default                --seeds-per-gpu 64   config 4 at N = 1 / weak scaling ("scaling": "weak")
+    --total-seeds 64       config 4 as worded: 64 seeds in total over the N ranks ("scaling": "strong")
+    --seeds-per-gpu 1      config 3: one instance x 8 line-search alphas
+The default run also times config 3 for a few iterations after the timed region and prints it under `extra`.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the library's own stream;
 `cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm) on a bounded sample.
@@ -23,7 +29,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP64_VECTOR_TFLOPS = 78.6  # half the guide's 157.3 TFLOP/s FP32 vector figure (an FP64 FMA issues at half the FP32 rate)
+
+# FP64 operations of one forward-dynamics evaluation of the 38-joint tree at each level of the mode-2 stencil, counted
+# from the operation sequences of csrc/rbd.h (tools/count_flops.py): a full articulated-body
+# evaluation, one that reuses the configuration-dependent part (velocity level), one that also reuses the (q, v) part
+FLOPS_FULL, FLOPS_VEL, FLOPS_TAU = 41_545, 15_052, 5_476
+
+
+def stencil_flops_per_bt(nv, fd_mode):
+    """second-order stage, per (instance, t)"""
+    tri = nv * (nv - 1) // 2
+    if fd_mode == 2:      # problem.hpp:152-298: (q,q) pairs | (q,v) + (v,v) pairs | (x,u) + (u,u) pairs, + 3 nv diagonal points
+        n_full, n_vel, n_tau = tri + nv, nv * nv + tri + nv, 2 * nv * nv + tri + nv
+        return n_full * FLOPS_FULL + n_vel * FLOPS_VEL + n_tau * FLOPS_TAU
+    return 0
 
 
 def parse():
@@ -32,22 +53,99 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seeds-per-gpu", type=int, default=64)
+    ap.add_argument("--total-seeds", type=int, default=0,
+                    help="strong scaling (BASELINE config 4 as worded): this many seeds in total, split over the ranks")
     ap.add_argument("--horizon", type=int, default=200)
     ap.add_argument("--mode", choices=["full", "gn"], default="full",
                     help="full = with second-order tensors (the reference's algorithm); gn = tensor-free variant")
+    ap.add_argument("--fd-mode", type=int, choices=[1, 2], default=2,
+                    help="second-order tensors: 2 = second differences of f (problem.hpp:152-298, FD f_x, f_u: the north star); "
+                         "1 = forward differences of the analytic jacobians (problem.hpp:67-150: what the reference's UR5 drivers use)")
     ap.add_argument("--n-alpha", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 (single instance) leg after the timed region")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="development: do not bracket the kernel launches with HIP events (no roofline / per-kernel times)")
-    ap.add_argument("--cpu-sample-steps", type=int, default=0, help="horizon of the CPU sample (0 = auto)")
+    ap.add_argument("--cpu-sample-steps", type=int, default=0, help="horizon of the CPU sample (0 = auto: 50)")
+    ap.add_argument("--cpu-iterations", type=int, default=5)
     return ap.parse_args()
+
+
+class Shard:
+    """The library's RCCL communicator (ddp_hip_comm_*, csrc/comm.cpp); the 128-byte id travels over torch.distributed."""
+
+    def __init__(self, capi, dist, torch, rank, world, device, red_dev):
+        import ctypes as C
+        self.C, self.L = C, capi.lib()
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            assert self.L.ddp_hip_comm_unique_id(uid) == 0
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=red_dev)
+        dist.broadcast(t, src=0)
+        uid = (C.c_ubyte * 128)(*t.cpu().tolist())
+        self.comm = C.c_void_p()
+        rc = self.L.ddp_hip_comm_init(uid, rank, world, device, C.byref(self.comm))
+        assert rc == 0, f"ddp_hip_comm_init: {rc}"
+
+    def best(self, cost, gidx):
+        C = self.C
+        c, i = C.c_double(), C.c_int64()
+        rc = self.L.ddp_hip_shard_best(self.comm, float(cost), int(gidx), C.byref(c), C.byref(i))
+        assert rc == 0, f"ddp_hip_shard_best: {rc}"
+        return c.value, i.value
+
+    def close(self):
+        self.L.ddp_hip_comm_destroy(self.comm)
+
+
+def make_instances(capi, a, model, seeds, device, T):
+    """a context holding one instance per global seed index in `seeds`"""
+    full = a.mode == "full"
+    fd_mode = a.fd_mode if full else 0
+    S = len(seeds)
+    spec = capi.ProblemSpec(model, T, dt=0.01, c=1.0, batch=S, fd_mode=fd_mode, first_order_fd=0 if (full and a.fd_mode == 1) else 1)
+    ctx = capi.Context(spec, device=device, flags=0 if full else capi.FLAG_NO_TENSORS)
+    nx, m = 2 * model.nv, model.nv
+    # synthetic inputs: x0 neutral, u_t ~ N(0, 0.1^2), seeded by the GLOBAL instance index (SURVEY.md 8d)
+    us = np.stack([0.1 * np.random.default_rng(0xDD9000 + 3000 + g).normal(size=T * m) for g in seeds])
+    ctx.upload("X", np.zeros((S, (T + 1) * nx)))
+    ctx.upload("U", us)
+    ctx.rollout()
+    ctx.upload("X_NEW", ctx.download("X"))
+    ctx.upload("U_NEW", us)
+    return ctx
+
+
+class Iterator:
+    def __init__(self, ctx, S, n_alpha):
+        self.ctx, self.S, self.n_alpha = ctx, S, n_alpha
+        self.reg = np.zeros(S)
+        self.mu = np.full(S, 1e2)
+        self.phase_ms = {"linearize": 0.0, "backward": 0.0, "forward": 0.0}
+
+    def step(self, timed):
+        ctx = self.ctx
+        t0 = time.perf_counter()
+        ctx.linearize()
+        t1 = time.perf_counter()
+        rc, self.reg, self.mu, restarts = ctx.backward(self.reg, self.mu)
+        t2 = time.perf_counter()
+        rc, step, dcost = ctx.forward(self.mu, n_alpha=self.n_alpha)
+        t3 = time.perf_counter()
+        self.reg = np.where(step >= 0.5, np.where(self.reg / 2 < 1e-5, 0.0, self.reg / 2), self.reg)   # ddp.hpp:819-824
+        ctx.swap_traj()                                      # ddp.hpp:826
+        if timed:
+            self.phase_ms["linearize"] += (t1 - t0) * 1e3
+            self.phase_ms["backward"] += (t2 - t1) * 1e3
+            self.phase_ms["forward"] += (t3 - t2) * 1e3
 
 
 def main():
     a = parse()
     import torch
     import torch.distributed as dist
-    from ddp_pinocchio_amd import capi, shard
+    from ddp_pinocchio_amd import capi
+    from ddp_pinocchio_amd import shard as shard_rule
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -66,50 +164,29 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    T, S = a.horizon, a.seeds_per_gpu
+    T = a.horizon
+    strong = a.total_seeds > 0
+    total = a.total_seeds if strong else a.seeds_per_gpu * world
+    # instance s -> rank s mod G (shard.instances_of_rank): the same rule in both modes
+    mine = shard_rule.instances_of_rank(total, rank, world)
+    S = len(mine)
+    assert S >= 1, "fewer seeds than ranks"
     full = a.mode == "full"
     model = capi.BuiltinModel(capi.BUILTIN_TREE38, 1)
-    spec = capi.ProblemSpec(model, T, dt=0.01, c=1.0, batch=S, fd_mode=2 if full else 0)
-    ctx = capi.Context(spec, device=local_rank, flags=0 if full else capi.FLAG_NO_TENSORS)
-    nv, nx, m = model.nv, 2 * model.nv, model.nv
-
-    # synthetic inputs: x0 neutral, u_t ~ N(0, 0.1^2), seeded by the GLOBAL instance index
-    xs = np.zeros((S, (T + 1) * nx))
-    us = np.zeros((S, T * m))
-    for s in range(S):
-        g = rank * S + s
-        us[s] = 0.1 * np.random.default_rng(0xDD9000 + 3000 + g).normal(size=T * m)
-    ctx.upload("X", xs)
-    ctx.upload("U", us)
-    ctx.rollout()
-    ctx.upload("X_NEW", ctx.download("X"))
-    ctx.upload("U_NEW", us)
-
-    reg = np.zeros(S)
-    mu = np.full(S, 1e2)
-    phase_ms = {"linearize": 0.0, "backward": 0.0, "forward": 0.0}
+    nv = model.nv
+    ctx = make_instances(capi, a, model, mine, local_rank, T)
+    info = ctx.info()
+    it = Iterator(ctx, S, a.n_alpha)
+    shard = Shard(capi, dist, torch, rank, world, local_rank, red_dev) if world > 1 else None
 
     def one_iteration(timed):
-        nonlocal reg, mu
-        t0 = time.perf_counter()
-        ctx.linearize()
-        t1 = time.perf_counter()
-        rc, reg, mu, restarts = ctx.backward(reg, mu)
-        t2 = time.perf_counter()
-        rc, step, dcost = ctx.forward(mu, n_alpha=a.n_alpha)
-        t3 = time.perf_counter()
-        reg = np.where(step >= 0.5, reg / 2, reg)            # ddp.hpp:819-824
-        reg = np.where(reg < 1e-5, 0.0, reg)
-        ctx.swap_traj()                                      # ddp.hpp:826
-        if world > 1:
+        it.step(timed)
+        if shard is not None:
             # the one exchange step: best-cost pick over all seeds of all ranks (two 8-byte RCCL all-reduces)
-            ctx.cost_seq_aug(0, mu)
+            ctx.cost_seq_aug(0, it.mu)
             costs = ctx.download("COSTS_OLD").sum(axis=1)
-            shard.best_of(costs, [rank * S + s for s in range(S)], device=red_dev)
-        if timed:
-            phase_ms["linearize"] += (t1 - t0) * 1e3
-            phase_ms["backward"] += (t2 - t1) * 1e3
-            phase_ms["forward"] += (t3 - t2) * 1e3
+            j = int(np.argmin(costs))
+            shard.best(costs[j], mine[j])
 
     for _ in range(a.warmup):
         one_iteration(False)
@@ -139,45 +216,92 @@ def main():
         elapsed = float(tt[0])
     ctx.profile_enable(False)
 
+    out = None
     if rank == 0:
         ms_a, n_a = ctx.profile_get(capi.K_BWD_ASSEMBLE)
-        ms_g, n_g = ctx.profile_get(capi.K_BWD_GAINS)
         ms_f, n_f = ctx.profile_get(capi.K_FWD_ROLLOUT)
         ms_l1, n_l1 = ctx.profile_get(capi.K_LIN_FIRST)
         ms_l2, n_l2 = ctx.profile_get(capi.K_LIN_SECOND)
+        steps = max(a.steps, 1)
         # algorithmic bytes of ONE bwd_contract (K3) launch = one timestep of every resident instance: the three
         # tensors read once (n^3 + n^2 m + n m^2 doubles) + V_x read + the contracted blocks written
         n_, m_ = 2 * nv, nv
         words = (n_ ** 3 + n_ * n_ * m_ + n_ * m_ * m_) + n_ + (n_ * n_ + m_ * n_ + m_ * m_)
-        bytes_per_launch = 8.0 * words * S if full else 0.0
+        launches_per_sweep = max(n_a / steps / T, 1e-9)           # > 1 when the batch is swept in groups on several streams
+        bytes_per_launch = 8.0 * words * S / launches_per_sweep if full else 0.0
         avg_s = (ms_a / max(n_a, 1)) * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        # the sweep-level figure SURVEY.md 8(d) / BASELINE.md 3 define: B_bwd of every resident instance / the time of the
+        # whole backward phase (K3 + K4 + launch gaps + the status read-back)
+        t_bwd = it.phase_ms["backward"] / steps * 1e-3
+        sweep_bytes = ctx.bwd_algorithmic_bytes() * S
+        sweep_gbs = sweep_bytes / t_bwd / 1e9 if t_bwd > 0 else 0.0
+        lin2_s = ms_l2 / steps * 1e-3
+        lin2_flops = stencil_flops_per_bt(nv, a.fd_mode if full else 0) * S * T
+        lin2_bytes = 8.0 * (n_ ** 3 + n_ * n_ * m_ + n_ * m_ * m_) * S * T if full else 0.0
         out = {
             "metric": "DDP iterations/sec (fwd+bwd sweep), Talos nq=38 T=200",
-            "value": world * S * a.steps / elapsed,
+            "value": total * a.steps / elapsed,
             "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Talos-like 38-DoF tree (nq=nv=38, n=76, m=38), T={T}, {S} seeds/GPU x {a.n_alpha} "
-                                   f"line-search alphas, {'full DDP (FD f_x,f_u + FD f_xx,f_ux,f_uu mode 2)' if full else 'tensor-free (Gauss-Newton) variant'}",
-                       "mode": a.mode, "horizon": T, "seeds_per_gpu": S, "n_alpha": a.n_alpha, "parallelism": f"seeds x{world}"},
-            "roofline": {"kernel": "bwd_contract (K3: V_x-contracted f_xx, f_ux, f_uu)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(S),
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": n_a},
-            "phases_ms_per_step": {k: v / a.steps for k, v in phase_ms.items()},
-            "kernels_ms_per_step": {"bwd_contract": ms_a / a.steps,
-                                    "bwd_riccati_and_gaps": (phase_ms["backward"] - ms_a) / a.steps, "fwd_rollout": ms_f / a.steps,
-                                    "lin_first": ms_l1 / a.steps, "lin_second": ms_l2 / a.steps},
+            "config": {"workload": f"Talos-like 38-DoF tree (nq=nv=38, n=76, m=38), T={T}, "
+                                   + (f"{total} seeds in total over {world} GPU(s)" if strong else f"{a.seeds_per_gpu} seeds/GPU")
+                                   + f" x {a.n_alpha} line-search alphas, "
+                                   + (("full DDP (FD f_x,f_u + FD f_xx,f_ux,f_uu mode 2)" if a.fd_mode == 2 else
+                                       "full DDP (analytic ABA derivatives + FD tensors mode 1)") if full else "tensor-free (Gauss-Newton) variant"),
+                       "mode": a.mode, "fd_mode": a.fd_mode if full else 0, "horizon": T, "seeds_per_gpu": S, "total_seeds": total,
+                       "n_alpha": a.n_alpha, "parallelism": f"seeds x{world}", "paths": info},
+            "roofline": {"kernel": "bwd_contract (K3: V_x-contracted f_xx, f_ux, f_uu)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(S / launches_per_sweep),
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": n_a,
+                         # whole backward phase: B_bwd x instances / t_backward (SURVEY.md 8d's definition)
+                         "sweep_achieved": sweep_gbs, "sweep_frac": sweep_gbs / HBM_PEAK_GBS,
+                         "sweep_bytes": sweep_bytes, "sweep_ms": t_bwd * 1e3},
+            "lin_second": {"bound": "fp64-valu", "flops": lin2_flops, "achieved": lin2_flops / lin2_s / 1e12 if lin2_s > 0 else 0.0,
+                           "peak": FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                           "frac": lin2_flops / lin2_s / 1e12 / FP64_VECTOR_TFLOPS if lin2_s > 0 else 0.0,
+                           "bytes_written": lin2_bytes, "write_gbs": lin2_bytes / lin2_s / 1e9 if lin2_s > 0 else 0.0, "ms": lin2_s * 1e3},
+            "phases_ms_per_step": {k: v / steps for k, v in it.phase_ms.items()},
+            "kernels_ms_per_step": {"bwd_contract": ms_a / steps,
+                                    "bwd_riccati_and_gaps": (it.phase_ms["backward"] - ms_a) / steps, "fwd_rollout": ms_f / steps,
+                                    "lin_first": ms_l1 / steps, "lin_second": ms_l2 / steps},
         }
+    ctx.close()
+    if rank == 0:
+        extra = {}
+        if world == 1 and not a.no_extra and S != 1:
+            extra["config3_single_instance"] = single_instance_leg(capi, a, model, local_rank, T)
+        if extra:
+            out["extra"] = extra
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, model)
         print(json.dumps(out), flush=True)
-    ctx.close()
-    if world > 1:
+    if shard is not None:
         dist.barrier()          # rank 0 may still be timing the CPU baseline: leave together
+        shard.close()
         dist.destroy_process_group()
+
+
+def single_instance_leg(capi, a, model, device, T):
+    """BASELINE config 3 as worded: ONE instance x 8 line-search alphas on one GPU (latency-bound: the two sequential
+    sweeps cost the same for 1 instance as for 64)"""
+    ctx = make_instances(capi, a, model, [0], device, T)
+    it = Iterator(ctx, 1, a.n_alpha)
+    it.step(False)
+    ctx.synchronize()
+    k = 3
+    t0 = time.perf_counter()
+    for _ in range(k):
+        it.step(True)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    ctx.close()
+    return {"workload": f"1 instance x {a.n_alpha} alphas, T={T}", "iterations_per_s": k / el, "ms_per_iteration": el / k * 1e3,
+            "phases_ms": {p: v / k for p, v in it.phase_ms.items()}}
 
 
 def pmc_traffic(S):
@@ -185,17 +309,20 @@ def pmc_traffic(S):
     under-count + WRITE_SIZE, separate --pmc runs: profiles/k3_traffic.json), valid for the profiled batch only"""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
-        return float(rec["bytes_per_launch"]) if int(rec["batch"]) == S else None
+        return float(rec["bytes_per_launch"]) if int(rec["batch"]) == int(round(S)) else None
     except Exception:
         return None
 
 
 def cpu_baseline(a, model):
-    """The CPU oracle (a port of the reference algorithm; the reference itself cannot be built here) timed on
-    this box's host cores, single thread like the reference (pinocchio_model.ipp:121), on a bounded sample:
-    one instance, a shorter horizon, one full iteration; scaled linearly in the horizon to T (every phase is
-    O(T))."""
+    """The CPU oracle (a port of the reference algorithm; the reference itself cannot be built here) timed on this box's
+    host cores on a bounded sample of the same workload: one instance, a shorter horizon (every phase is O(T): scaled
+    linearly to T), real consecutive DDP iterations (linearise -> backward -> forward -> swap), median over
+    --cpu-iterations.  Legs: 1 thread "reference-like" (per-step heap temporaries as
+    ddp_bwd.ipp:27-83; the headline `value`, since the reference is single-threaded: pinocchio_model.ipp:121), 1 thread
+    "best-effort" (pre-allocated workspaces), and all host cores with one instance per thread."""
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import binding
     from oracle.binding import Oracle
     tmp = os.path.join(tempfile.gettempdir(), f"libddp_oracle_native_{os.getpid()}.so")
@@ -204,24 +331,51 @@ def cpu_baseline(a, model):
     except Exception:
         path = None
     full = a.mode == "full"
-    Ts = a.cpu_sample_steps or a.horizon
-    o = Oracle(model, Ts, dt=0.01, c=1.0, fd_mode=2 if full else 0, lib_path=path)
-    us = 0.1 * np.random.default_rng(0xDD9000 + 3000).normal(size=Ts * model.nv)
-    xs = o.rollout(np.zeros(2 * model.nv), us)
-    mults = o.alloc_affine(0)
-    t0 = time.perf_counter()
-    d = o.compute_derivatives(xs, us)
-    t1 = time.perf_counter()
-    bw = o.backward(d, xs, mults, reg=0.0, mu=1e2, trace=False, heap_like=True)
-    t2 = time.perf_counter()
-    o.forward(xs, us, mults, bw["fb"], bw["mu"])
-    t3 = time.perf_counter()
+    Ts = a.cpu_sample_steps or min(50, a.horizon)
     scale = a.horizon / Ts
-    total = (t3 - t0) * scale
-    return {"value": 1.0 / total, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"1 instance, horizon {Ts} of {a.horizon} (scaled x{scale:g}), one iteration: linearise "
-                      f"{(t1 - t0):.2f}s backward {(t2 - t1):.3f}s forward {(t3 - t2):.3f}s; gcc -O3 -march=native, 1 thread",
-            "cpu_seconds": t3 - t0}
+    fd_mode = a.fd_mode if full else 0
+    fo_fd = 0 if (full and a.fd_mode == 1) else 1
+
+    def run(seed, iters, heap_like):
+        o = Oracle(model, Ts, dt=0.01, c=1.0, fd_mode=fd_mode, first_order_fd=fo_fd, lib_path=path)
+        us = 0.1 * np.random.default_rng(0xDD9000 + 3000 + seed).normal(size=Ts * model.nv)
+        xs = o.rollout(np.zeros(2 * model.nv), us)
+        mults = o.alloc_affine(0)
+        reg, mu = 0.0, 1e2
+        times = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            d = o.compute_derivatives(xs, us)
+            t1 = time.perf_counter()
+            bw = o.backward(d, xs, mults, reg=reg, mu=mu, trace=False, heap_like=heap_like)
+            t2 = time.perf_counter()
+            step, xs_new, us_new, _ = o.forward(xs, us, mults, bw["fb"], bw["mu"])
+            t3 = time.perf_counter()
+            reg, mu = bw["reg"], bw["mu"]
+            if step >= 0.5:
+                reg = 0.0 if reg / 2 < 1e-5 else reg / 2
+            xs, us = xs_new, us_new
+            times.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+        return np.array(times)
+
+    t_all0 = time.perf_counter()
+    ref_like = run(0, a.cpu_iterations, True)
+    best = run(0, max(2, a.cpu_iterations // 2), False)
+    cores = os.cpu_count() or 1
+    tp0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:           # ctypes releases the GIL: one instance per thread
+        list(ex.map(lambda s: run(s, 1, False), range(cores)))
+    all_cores_s = time.perf_counter() - tp0
+    med = np.median(ref_like, axis=0) * scale
+    med_best = np.median(best, axis=0) * scale
+    return {"value": 1.0 / med[0], "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"1 instance, horizon {Ts} of {a.horizon} (times scaled x{scale:g}), median of {a.cpu_iterations} consecutive "
+                      f"iterations: linearise {med[1]:.2f}s backward {med[2]:.3f}s forward {med[3]:.3f}s; reference-like heap temporaries; "
+                      f"gcc -O3 -march=native, 1 thread",
+            "best_effort_1_thread": {"value": 1.0 / med_best[0], "sample": "pre-allocated workspaces, same sample"},
+            "all_cores": {"value": cores / (all_cores_s * scale), "cores": cores,
+                          "sample": f"{cores} instances, one per thread, one iteration each at horizon {Ts} (scaled)"},
+            "cpu_seconds": time.perf_counter() - t_all0}
 
 
 if __name__ == "__main__":

@@ -46,6 +46,7 @@ EXPORTS = [
     "ddp_hip_update_origin", "ddp_hip_optimality", "ddp_hip_update_multipliers", "ddp_hip_profile_enable",
     "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_comm_unique_id",
     "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_builtin_model",
+    "ddp_hip_batch", "ddp_hip_set_active", "ddp_hip_solve", "ddp_hip_ctx_info",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -68,6 +69,23 @@ class Problem(C.Structure):
         ("frame_joint", C.c_int32), ("frame_off", C.c_double * 3),
         ("first_order_fd", C.c_int32), ("fd_mode", C.c_int32),
     ]
+
+
+class SolverParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int64), ("optimality_stopping_threshold", C.c_double), ("mu", C.c_double),
+                ("reg", C.c_double), ("w", C.c_double), ("n", C.c_double), ("n_alpha", C.c_int32), ("pad_", C.c_int32),
+                ("max_restarts", C.c_int64)]
+
+
+class SolveLog(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("result", C.c_int32), ("pad_", C.c_int32), ("mu", C.c_double), ("reg", C.c_double),
+                ("w", C.c_double), ("n", C.c_double), ("last_step", C.c_double), ("opt_obj", C.c_double),
+                ("opt_constr", C.c_double)]
+
+
+class Info(C.Structure):
+    _fields_ = [("device", C.c_int32), ("lin_path", C.c_int32), ("first_order", C.c_int32), ("bwd_path", C.c_int32),
+                ("fwd_path", C.c_int32), ("has_tensors", C.c_int32), ("hbm_bytes", C.c_int64)]
 
 
 class ModelStorage(C.Structure):
@@ -127,6 +145,11 @@ def lib():
     L.ddp_hip_comm_destroy.argtypes = [C.c_void_p]
     L.ddp_hip_shard_best.argtypes = [C.c_void_p, C.c_double, C.c_int64, _dp, _lp]
     L.ddp_hip_builtin_model.argtypes = [C.c_int, C.c_uint64, C.POINTER(ModelStorage), C.POINTER(Model)]
+    L.ddp_hip_batch.restype = C.c_int64
+    L.ddp_hip_batch.argtypes = [C.c_void_p]
+    L.ddp_hip_set_active.argtypes = [C.c_void_p, _ip]
+    L.ddp_hip_solve.argtypes = [C.c_void_p, C.POINTER(SolverParams), C.POINTER(SolveLog)]
+    L.ddp_hip_ctx_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     _lib = L
     return L
 
@@ -298,6 +321,29 @@ class Context:
     def update_multipliers(self, mu):
         mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
         _check(lib().ddp_hip_update_multipliers(self._h, _ptr(mu)), "update_multipliers")
+
+    def set_active(self, active=None):
+        """active: [batch] of 0 / 1 (None = all): inactive instances are frozen (ddp_hip_set_active)"""
+        if active is None:
+            _check(lib().ddp_hip_set_active(self._h, None), "set_active")
+            return
+        a = np.ascontiguousarray(np.broadcast_to(active, (self.batch,)), dtype=np.int32)
+        _check(lib().ddp_hip_set_active(self._h, a.ctypes.data_as(_ip)), "set_active")
+
+    def solve(self, max_iterations, threshold, mu, reg, w, n, n_alpha=8, max_restarts=1000):
+        """solve<M> (ddp.hpp:745-842) of every instance (ddp_hip_solve); returns (rc, dict of per-instance arrays)"""
+        sp = SolverParams(int(max_iterations), float(threshold), float(mu), float(reg), float(w), float(n), int(n_alpha), 0,
+                          int(max_restarts))
+        logs = (SolveLog * self.batch)()
+        rc = _check(lib().ddp_hip_solve(self._h, C.byref(sp), logs), "solve")
+        out = {k: np.array([getattr(l, k) for l in logs]) for k, _ in SolveLog._fields_ if k != "pad_"}
+        out["done"] = out["result"] == 1
+        return rc, out
+
+    def info(self):
+        i = Info()
+        _check(lib().ddp_hip_ctx_info(self._h, C.byref(i)), "ctx_info")
+        return {k: getattr(i, k) for k, _ in Info._fields_}
 
     def profile_enable(self, on=True, kernels=None):
         """on: every kernel class; kernels: an iterable of K_* ids to bracket only those"""

@@ -425,12 +425,6 @@ int launch_sweep_split(ddp_hip_ctx* ctx, const BwdParams& p) {
   const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
   const size_t lds_c = sizeof(double) * (size_t)(NC + (NC + MC) * cn_max + 2 * (NC / 2 + 1) * MC);
   const size_t lds_r = sizeof(double) * (size_t)(2 * NC * (NC + MC));
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_riccati<NC, MC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense0<NC, MC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-    attr_set = true;
-  }
   hipLaunchKernelGGL(bwd_init, dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p);
   hipLaunchKernelGGL((bwd_dense0<NC, MC>), dim3((unsigned)d.batch), dim3(BSR), lds_r, ctx->stream, p);
   for (int64_t t = d.T - 1; t >= 0; --t) {
@@ -476,6 +470,13 @@ int bwd_setup(ddp_hip_ctx* ctx) {
   for (int64_t c = 0; c < n; c += cbx) jobs.push_back(BwdJob{0, (int32_t)c, (int32_t)((n - c) < cbx ? (n - c) : cbx), 0});
   for (int64_t c = 0; c < m; c += cbu) jobs.push_back(BwdJob{1, (int32_t)c, (int32_t)((m - c) < cbu ? (m - c) : cbu), 0});
   ctx->njobs = (int32_t)jobs.size();
+  if (n == 76 && m == 38) {
+    // K4 needs more than the default 64 KB of dynamic LDS.  The attribute is per device: it is set here, with the
+    // context's device current, by every context (not behind a process-wide flag)
+    const size_t lds_r = sizeof(double) * (size_t)(2 * 76 * (76 + 38));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_riccati<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense0<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+  }
   HIP_TRY(hipMalloc(&ctx->jobs_d, sizeof(BwdJob) * jobs.size()));
   HIP_TRY(hipMemcpy(ctx->jobs_d, jobs.data(), sizeof(BwdJob) * jobs.size(), hipMemcpyHostToDevice));
   return DDP_HIP_OK;
@@ -502,7 +503,9 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
 
   HIP_TRY(hipMemcpyAsync(ctx->reg_d, reg_io, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->mu_d, mu_io, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->status_d, 0, sizeof(int32_t) * (size_t)B, ctx->stream));
+  std::vector<int32_t> status((size_t)B);
+  for (int64_t b = 0; b < B; ++b) status[(size_t)b] = ctx->active_h[(size_t)b] ? 0 : 2;   // a frozen instance counts as done
+  HIP_TRY(hipMemcpyAsync(ctx->status_d, status.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->restarts_d, 0, sizeof(int64_t) * (size_t)B, ctx->stream));
 
   const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
@@ -510,7 +513,6 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
   const size_t lds_g = gains_lds_bytes(ctx);
   if (lds_a > 160 * 1024 || lds_g > 160 * 1024) return DDP_HIP_E_UNSUPPORTED;
 
-  std::vector<int32_t> status((size_t)B);
   bool any_restart = false;
   int rc = DDP_HIP_OK;
   for (int64_t attempt = 0;; ++attempt) {

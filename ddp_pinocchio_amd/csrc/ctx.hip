@@ -1,6 +1,7 @@
 // ctx.hip -- context life cycle, resident sequences, profiling.  gfx950 only.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <limits>
@@ -213,6 +214,7 @@ extern "C" int ddp_hip_create(const ddp_hip_problem* prob, int device, uint32_t 
   if (!ctx) return DDP_HIP_E_HIP;
   ctx->device = device;
   ctx->flags = flags;
+  ctx->active_h.assign((size_t)prob->batch, 1);
   Dims& d = ctx->d;
   d.T = prob->T; d.nv = mo.nv; d.n = 2 * (int64_t)mo.nv; d.m = mo.nv; d.nx = 2 * (int64_t)mo.nv; d.batch = prob->batch;
   ctx->ne_h.assign((size_t)d.T, 0);
@@ -318,6 +320,8 @@ extern "C" int ddp_hip_synchronize(ddp_hip_ctx* ctx) {
   return DDP_HIP_OK;
 }
 
+extern "C" int64_t ddp_hip_batch(const ddp_hip_ctx* ctx) { return ctx ? ctx->d.batch : -1; }
+
 extern "C" int64_t ddp_hip_seq_size(const ddp_hip_ctx* ctx, int seq) {
   if (!ctx || seq < 0 || seq >= DDP_HIP_SEQ_COUNT) return -1;
   return ctx->seq[seq].size;
@@ -366,8 +370,45 @@ extern "C" int ddp_hip_fill(ddp_hip_ctx* ctx, int seq, double value) {
   return fill_device(ctx, ctx->seq[seq].ptr, ctx->seq[seq].size * ctx->d.batch, value);
 }
 
+extern "C" int ddp_hip_set_active(ddp_hip_ctx* ctx, const int32_t* active) {
+  if (!ctx) return DDP_HIP_E_ARG;
+  ctx->all_active = true;
+  for (int64_t b = 0; b < ctx->d.batch; ++b) {
+    ctx->active_h[(size_t)b] = (!active || active[b]) ? 1 : 0;
+    if (!ctx->active_h[(size_t)b]) ctx->all_active = false;
+  }
+  return DDP_HIP_OK;
+}
+
+extern "C" int ddp_hip_ctx_info(const ddp_hip_ctx* ctx, ddp_hip_info* out) {
+  if (!ctx || !out) return DDP_HIP_E_ARG;
+  const Dims& d = ctx->d;
+  out->device = ctx->device;
+  out->lin_path = ctx->model_h.kind == DDP_HIP_MODEL_PENDULUM ? 0 : (ctx->lin_static ? 1 + ctx->lin_static : 1);
+  out->first_order = ctx->model_h.kind == DDP_HIP_MODEL_PENDULUM ? 0 : (ctx->model_h.first_order_fd ? 1 : 2);
+  out->bwd_path = (d.n == 76 && d.m == 38 && getenv("DDP_HIP_GENERIC_BWD") == nullptr) ? 1 : 0;
+  out->fwd_path = (ctx->model_h.kind == DDP_HIP_MODEL_TREE && d.Etot == 0 && d.nv == 38 && ctx->model_h.max_level_width <= 8 &&
+                   getenv("DDP_HIP_FWD_SCRATCH") == nullptr) ? 1 : 0;
+  out->has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
+  int64_t bytes = 0;
+  for (int s = 0; s < DDP_HIP_SEQ_COUNT; ++s)
+    if (ctx->seq[s].ptr) bytes += 8 * ctx->seq[s].size * d.batch;
+  out->hbm_bytes = bytes;
+  return DDP_HIP_OK;
+}
+
 extern "C" int ddp_hip_swap_traj(ddp_hip_ctx* ctx) {
   if (!ctx) return DDP_HIP_E_ARG;
+  if (!ctx->all_active) {
+    // a frozen instance keeps its trajectory: it is cloned into the buffers that become (X, U)
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t sx = ctx->seq[DDP_HIP_SEQ_X].size, su = ctx->seq[DDP_HIP_SEQ_U].size;
+    for (int64_t b = 0; b < ctx->d.batch; ++b) {
+      if (ctx->active_h[(size_t)b]) continue;
+      HIP_TRY(hipMemcpyAsync(ctx->seq[DDP_HIP_SEQ_X_NEW].ptr + b * sx, ctx->seq[DDP_HIP_SEQ_X].ptr + b * sx, sizeof(double) * (size_t)sx, hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->seq[DDP_HIP_SEQ_U_NEW].ptr + b * su, ctx->seq[DDP_HIP_SEQ_U].ptr + b * su, sizeof(double) * (size_t)su, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
   // swap(traj, new_traj), ddp.hpp:826: the resident buffers trade places, nothing moves in HBM
   std::swap(ctx->seq[DDP_HIP_SEQ_X].ptr, ctx->seq[DDP_HIP_SEQ_X_NEW].ptr);
   std::swap(ctx->seq[DDP_HIP_SEQ_U].ptr, ctx->seq[DDP_HIP_SEQ_U_NEW].ptr);

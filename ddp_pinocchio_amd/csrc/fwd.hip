@@ -260,11 +260,15 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
 // trajectory becomes (X_NEW, U_NEW).  grid = batch.
 __global__ void select_kernel(FwdParams p) {
   const int b = blockIdx.x;
-  if (p.state[b] != 0) return;
+  // every wave must see the state as it was at launch: thread 0 rewrites it below, and a wave scheduled late would
+  // otherwise leave before its share of the trajectory copy
+  __shared__ int s_state, s_win, s_last;
+  if (threadIdx.x == 0) s_state = p.state[b];
+  __syncthreads();
+  if (s_state != 0) return;
   const int na = p.n_alpha;
   const int64_t T = p.d.T;
   const int nx = (int)p.d.nx, nu = (int)p.d.m;
-  __shared__ int s_win, s_last;
   if (threadIdx.x == 0) {
     int win = -1, last = -1;
     for (int a = 0; a < na; ++a) {
@@ -338,6 +342,11 @@ int fwd_setup(ddp_hip_ctx* ctx) {
   HIP_TRY(hipMalloc(&ctx->step_d, sizeof(double) * (size_t)B));
   HIP_TRY(hipMalloc(&ctx->fw_dcost_acc_d, sizeof(double) * (size_t)B));
   HIP_TRY(hipMalloc(&ctx->fw_state_d, sizeof(int32_t) * (size_t)B));
+  if (d.nv == 38) {
+    // per device, by every context (the attribute is not process-wide)
+    const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   return DDP_HIP_OK;
 }
 
@@ -392,12 +401,13 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
   const int64_t B = d.batch;
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemcpyAsync(ctx->mu_d, mu, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->fw_state_d, 0, sizeof(int32_t) * (size_t)B, ctx->stream));
+  std::vector<int32_t> state((size_t)B);
+  for (int64_t b = 0; b < B; ++b) state[(size_t)b] = ctx->active_h[(size_t)b] ? 0 : 1;   // a frozen instance is not searched
+  HIP_TRY(hipMemcpyAsync(ctx->fw_state_d, state.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
   FwdParams p = make_params(ctx);
   p.n_alpha = n_alpha;
   int rc = launch_cost(ctx, p, 0);                                   // ddp_fwd.ipp:24-26
   if (rc != DDP_HIP_OK) return rc;
-  std::vector<int32_t> state((size_t)B);
   const int bs = 64;
   const unsigned grid = (unsigned)((B * n_alpha + bs - 1) / bs);
   bool floor_hit = false;
@@ -409,11 +419,6 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
                           ctx->model_h.max_level_width <= 8 && getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
     if (lat_path) {
       const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));
-      static bool attr = false;
-      if (!attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-      }
       hipLaunchKernelGGL((forward_kernel_lat<38>), dim3((unsigned)B), dim3(64), lds, ctx->stream, p);
     } else {
 #define CALL(NJ) hipLaunchKernelGGL((forward_kernel<NJ>), dim3(grid), dim3(bs), 0, ctx->stream, p)

@@ -113,6 +113,11 @@ struct ddp_hip_ctx {
   hipEvent_t lin_ev_up[2] = {nullptr, nullptr}, lin_ev_dn[2] = {nullptr, nullptr};
   int lin_static = 0;          // id of the compiled-in topology the model's tree matches (lin_static.hip), 0 = none
 
+  // per-instance activity (ddp_hip_set_active): an inactive instance is frozen -- the sweeps skip it and swap_traj
+  // keeps its trajectory (solve<M> returns an instance at its first optimum, ddp.hpp:799-800)
+  std::vector<int32_t> active_h;   // [batch], 1 = active
+  bool all_active = true;
+
   uint32_t profile_mask = 0;   // bit (1 + kernel_id): that kernel class is bracketed by HIP events
   ProfSlot prof[DDP_HIP_K_COUNT];
 };

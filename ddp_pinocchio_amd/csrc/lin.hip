@@ -704,10 +704,11 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
   // static-topology path: the q- / v-caches of the mode-2 stencil also serve the first order (base configuration and
   // base (q, v)), so they are built ahead of whichever stage comes first
   bool caches_built = false;
+  int static_rc = DDP_HIP_OK;
   auto build_caches = [&]() {
     if (caches_built || !p.qcache) return;
     const int nv = (int)d.nv;
-    if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CACHE") == nullptr) lin_static_launch(ctx, p, 5);
+    if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CACHE") == nullptr) { const int rc_ = lin_static_launch(ctx, p, 5); if (rc_ != DDP_HIP_OK) static_rc = rc_; }
     else {
       hipLaunchKernelGGL((lin_qcache_kernel<NJ>), dim3(blocks_for(BT * (nv + 1))), dim3(LBS), 0, ctx->stream, p);
       hipLaunchKernelGGL((lin_vcache_kernel<NJ>), dim3(blocks_for(BT * (2 * nv + 1))), dim3(LBS), 0, ctx->stream, p);
@@ -718,7 +719,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     prof_begin(ctx, DDP_HIP_K_LIN_FIRST);
     hipLaunchKernelGGL((lin_base_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
     if (ctx->model_h.first_order_fd) {
-      if (ctx->lin_static && p.qcache && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); lin_static_launch(ctx, p, 0); }
+      if (ctx->lin_static && p.qcache && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); { const int rc_ = lin_static_launch(ctx, p, 0); if (rc_ != DDP_HIP_OK) return rc_; } }
       else hipLaunchKernelGGL((lin_first_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
     }
     prof_end(ctx, DDP_HIP_K_LIN_FIRST);
@@ -730,14 +731,14 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         const int nv = (int)d.nv;
         const int64_t TRI = (int64_t)nv * (nv - 1) / 2, Pv = (int64_t)nv * nv + TRI, Pu = 2 * (int64_t)nv * nv + TRI;
         build_caches();
-        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_DIAG") == nullptr) lin_static_launch(ctx, p, 4);
+        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_DIAG") == nullptr) { const int rc_ = lin_static_launch(ctx, p, 4); if (rc_ != DDP_HIP_OK) return rc_; }
         else hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
         // torque level first: on the static path its row kernel also forms the diagonal entries of the q and v directions
-        if (ctx->lin_static) lin_static_launch(ctx, p, 3);
+        if (ctx->lin_static) { const int rc_ = lin_static_launch(ctx, p, 3); if (rc_ != DDP_HIP_OK) return rc_; }
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 3>), dim3(blocks_for(BT * Pu)), dim3(LBS), 0, ctx->stream, p);
-        if (ctx->lin_static) lin_static_launch(ctx, p, 2);
+        if (ctx->lin_static) { const int rc_ = lin_static_launch(ctx, p, 2); if (rc_ != DDP_HIP_OK) return rc_; }
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 2>), dim3(blocks_for(BT * Pv)), dim3(LBS), 0, ctx->stream, p);
-        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CFG") == nullptr) lin_static_launch(ctx, p, 1);
+        if (ctx->lin_static && getenv("DDP_HIP_NO_STATIC_CFG") == nullptr) { const int rc_ = lin_static_launch(ctx, p, 1); if (rc_ != DDP_HIP_OK) return rc_; }
         else hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 1>), dim3(blocks_for(BT * TRI)), dim3(LBS), 0, ctx->stream, p);
       } else {
         hipLaunchKernelGGL((lin_diag_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
@@ -794,7 +795,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     }
   }
   HIP_TRY(hipGetLastError());
-  return DDP_HIP_OK;
+  return static_rc;
 }
 
 }  // namespace

@@ -25,5 +25,5 @@ constexpr int LBS = 64;
 // static-topology second-order path (lin_static.hip): returns non-zero when the model's tree matches a compiled-in
 // topology; the launcher covers the velocity- and torque-level stencil points of finite_diff_hessian_compute mode 2
 int lin_static_supported(const DevModel& m);   // 0: none, else the id of the compiled-in topology
-void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level);
+int lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level);   // DDP_HIP_OK or an error code
 int64_t lin_static_ws_per_bt(const DevModel& m);

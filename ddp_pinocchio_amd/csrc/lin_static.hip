@@ -1403,7 +1403,7 @@ int64_t lin_static_ws_per_bt(const DevModel& m) {
 
 // level 3: torque-level points (replaces lin_offdiag_kernel<NJ, 3>)
 template <class T>
-static void lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level) {
+static int lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level) {
   const int64_t BT = ctx->d.batch * ctx->d.T;
   constexpr int nv = T::N, TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS;
   if (level == 3) {
@@ -1435,22 +1435,26 @@ static void lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level)
       const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
       const int w = k & 1;
       double* ws = w ? ctx->lin_qws2 : ctx->lin_qws;
-      if (k >= 2) (void)hipStreamWaitEvent(s0, ctx->lin_ev_dn[w], 0);           // slice k-2 is done with this workspace
+      // a failed wait / record would silently turn into a race on the shared workspace: every return code is checked
+      if (k >= 2) HIP_TRY(hipStreamWaitEvent(s0, ctx->lin_ev_dn[w], 0));        // slice k-2 is done with this workspace
       hipLaunchKernelGGL((lin_static_cfg_up_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, s0, p, p.model, p.qcache, p.x, p.u, ws, bt0);
-      (void)hipEventRecord(ctx->lin_ev_up[w], s0);
-      (void)hipStreamWaitEvent(s1, ctx->lin_ev_up[w], 0);
+      HIP_TRY(hipEventRecord(ctx->lin_ev_up[w], s0));
+      HIP_TRY(hipStreamWaitEvent(s1, ctx->lin_ev_up[w], 0));
       hipLaunchKernelGGL((lin_static_cfg_down_kernel<T>), dim3((unsigned)(nb * GU)), dim3(LBS), 0, s1, p, p.model, p.qcache, p.x, p.u, ws, bt0);
-      (void)hipEventRecord(ctx->lin_ev_dn[w], s1);
+      HIP_TRY(hipEventRecord(ctx->lin_ev_dn[w], s1));
     }
-    if (k >= 1) (void)hipStreamWaitEvent(s0, ctx->lin_ev_dn[0], 0);
-    if (k >= 2) (void)hipStreamWaitEvent(s0, ctx->lin_ev_dn[1], 0);
+    if (k >= 1) HIP_TRY(hipStreamWaitEvent(s0, ctx->lin_ev_dn[0], 0));
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(s0, ctx->lin_ev_dn[1], 0));
   } else if (level == 2) {
     hipLaunchKernelGGL((lin_static_vel_kernel<T, true>), dim3((unsigned)(BT * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_vel_kernel<T, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
   }
+  HIP_TRY(hipGetLastError());
+  return DDP_HIP_OK;
 }
 
-void lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
-  if (ctx->lin_static == 1) lin_static_launch_t<TopoTalos38>(ctx, p, level);
-  else if (ctx->lin_static == 2) lin_static_launch_t<TopoChain6>(ctx, p, level);
+int lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
+  if (ctx->lin_static == 1) return lin_static_launch_t<TopoTalos38>(ctx, p, level);
+  if (ctx->lin_static == 2) return lin_static_launch_t<TopoChain6>(ctx, p, level);
+  return DDP_HIP_E_UNSUPPORTED;
 }

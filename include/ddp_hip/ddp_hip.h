@@ -20,6 +20,7 @@
  *   update_origin            detail/mat_seq_common.hpp:62-89        ddp_hip_update_origin
  *   optimality_obj / _constr ddp.hpp:576-627, 516-523               ddp_hip_optimality
  *   multiplier update        ddp.hpp:680-688 (in update_derivatives) ddp_hip_update_multipliers
+ *   solve<M>                 ddp.hpp:745-842                        ddp_hip_solve (+ ddp_hip_set_active)
  *   (new: multi-seed shard)                           ddp_hip_comm_* / ddp_hip_shard_best
  *
  * Conventions
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDP_HIP_ABI_VERSION 1
+#define DDP_HIP_ABI_VERSION 2
 
 enum {
   DDP_HIP_OK = 0,
@@ -128,6 +129,7 @@ int ddp_hip_destroy(ddp_hip_ctx* ctx);
 void* ddp_hip_stream(ddp_hip_ctx* ctx);
 int ddp_hip_synchronize(ddp_hip_ctx* ctx);
 
+int64_t ddp_hip_batch(const ddp_hip_ctx* ctx);                       /* instances resident in the context */
 int64_t ddp_hip_seq_size(const ddp_hip_ctx* ctx, int seq);           /* elements per instance */
 double* ddp_hip_device_ptr(ddp_hip_ctx* ctx, int seq);               /* [batch][seq_size], device memory */
 int ddp_hip_upload(ddp_hip_ctx* ctx, int seq, const double* host, int64_t first_instance, int64_t n_instances);
@@ -173,6 +175,45 @@ int ddp_hip_update_origin(ddp_hip_ctx* ctx, int which);
 int ddp_hip_optimality(ddp_hip_ctx* ctx, const double* mu, double* obj_out, double* constr_out);
 /* p.val += mu (eq + eq_u k), p.jac += mu (eq_x + eq_u K) (ddp.hpp:680-688); mu: host [batch] */
 int ddp_hip_update_multipliers(ddp_hip_ctx* ctx, const double* mu);
+
+/* Per-instance activity.  solve<M> returns an instance the moment it reaches its optimum (ddp.hpp:799-800); in a batch
+ * the others go on.  An inactive instance is frozen: ddp_hip_backward / ddp_hip_forward skip it (its reg / mu / step
+ * entries are left as they are) and ddp_hip_swap_traj keeps its (X, U).  active: host [batch] of 0 / 1, NULL = all. */
+int ddp_hip_set_active(ddp_hip_ctx* ctx, const int32_t* active);
+
+/* solve<primal_dual_affine_multipliers> (ddp.hpp:745-842) for every instance of the context, each with the reference's
+ * per-problem semantics: an instance stops at its first optimum (result 1, `iterations` = the iteration that found it)
+ * or after max_iterations (result 0), whatever its batch-mates do.  In: X / U the initial trajectory, X_NEW / U_NEW a
+ * clone of it (ddp.hpp:752), MULT_* the initial multipliers (val 0, jac the seed the reference draws with setRandom(),
+ * origin = X: ddp.hpp:759-764).  Out: the final trajectory in X / U, the feedback in FB_*, log[batch]. */
+typedef struct ddp_hip_solver_params {   /* solver_parameters_t, ddp.hpp:42-50 */
+  int64_t max_iterations;
+  double optimality_stopping_threshold;
+  double mu, reg, w, n;
+  int32_t n_alpha;        /* line-search candidates per round (1 = the reference's sequential halving) */
+  int32_t pad_;
+  int64_t max_restarts;   /* bound on the reference's unbounded while(!success) of backward_pass */
+} ddp_hip_solver_params;
+typedef struct ddp_hip_solve_log {
+  int64_t iterations;
+  int32_t result;         /* 0 max_iterations reached, 1 optimum attained */
+  int32_t pad_;
+  double mu, reg, w, n, last_step, opt_obj, opt_constr;
+} ddp_hip_solve_log;
+int ddp_hip_solve(ddp_hip_ctx* ctx, const ddp_hip_solver_params* params, ddp_hip_solve_log* log);
+
+/* Which implementation each phase of this context runs (a model whose tree matches no compiled-in topology gets the
+ * run-time-tree stencil kernels, several times slower: visible here instead of silently) */
+typedef struct ddp_hip_info {
+  int32_t device;
+  int32_t lin_path;       /* 0 closed form (pendulum), 1 run-time-tree kernels (any topology), 2 static TopoTalos38, 3 static TopoChain6 */
+  int32_t first_order;    /* 0 analytic (pendulum_model.hpp:116-130), 1 forward FD (north star), 2 analytic ABA derivatives */
+  int32_t bwd_path;       /* 0 run-time-shaped bwd_assemble / bwd_gains, 1 split K3 bwd_contract / K4 bwd_riccati */
+  int32_t fwd_path;       /* 0 one lane per rollout, 1 latency path (one workgroup per instance) */
+  int32_t has_tensors;
+  int64_t hbm_bytes;      /* bytes of the resident sequences */
+} ddp_hip_info;
+int ddp_hip_ctx_info(const ddp_hip_ctx* ctx, ddp_hip_info* out);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 enum ddp_hip_kernel_id {

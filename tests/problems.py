@@ -47,3 +47,23 @@ def initial_trajectory(oracle, model, seed, u_sigma=0.1):
     us = u_sigma * rng.normal(size=oracle.T * model.nv)
     xs = oracle.rollout(x0, us)
     return x0, us, xs
+
+
+def held_trajectory(oracle, model, seed, q0_sigma=0.3, u_sigma=0.01, kp=100.0, kd=20.0):
+    """A well-conditioned long trajectory: the robot holds a random posture q0 under computed-torque control
+    u_t = RNEA(q_t, v_t, -kp (q_t - q0) - kd v_t) + N(0, u_sigma^2).  (Open-loop noise on the light UR5-like wrist is a
+    free fall: |f_x| ~ 100 per step, and a 200-step backward recursion through it amplifies one ulp to 1e-7 whatever the
+    implementation.)  Returns (x0, us, xs) with xs the oracle's rollout of us."""
+    rng = np.random.default_rng(seed)
+    nv, T = model.nv, oracle.T
+    q0 = q0_sigma * rng.normal(size=nv)
+    x = np.concatenate([q0, np.zeros(nv)])
+    x0 = x.copy()
+    us = np.zeros(T * nv)
+    for t in range(T):
+        q, v = x[:nv], x[nv:]
+        u = oracle.rnea(q, v, -kp * (q - q0) - kd * v) + u_sigma * rng.normal(size=nv)
+        us[t * nv:(t + 1) * nv] = u
+        x = oracle.eval_f(x, u)
+    xs = oracle.rollout(x0, us)
+    return x0, us, xs

@@ -77,3 +77,38 @@ def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
     scale = max(np.max(np.abs(b)) if b.size else 0.0, 1e-300)
     return float(np.max(np.abs(a - b)) / scale) if a.size else 0.0
+
+
+def stepwise_backward_check(oracle_factory, o, d, xs, mults, reg, mu, Vx_tr, Vxx_tr, k_dev, K_dev, ts):
+    """Per-step parity of the backward recursion, immune to the conditioning of the whole sweep: for every t in `ts` the
+    oracle redoes step t alone (ddp_bwd.ipp:61-146) from the DEVICE's own V_x(t+1), V_xx(t+1) (its trace) and must land on
+    the device's k_t, K_t, V_x(t), V_xx(t).  oracle_factory(ne_t, target_t) builds a one-step oracle of the same problem.
+    Returns the largest relative error seen over (k, K, V_x, V_xx)."""
+    T, n, m, nx = o.T, o.n, o.m, o.nx
+    Epre = np.concatenate([[0], np.cumsum(o.ne)]).astype(np.int64)
+    worst = 0.0
+    for t in ts:
+        e, E0 = int(o.ne[t]), int(Epre[t])
+        o1 = oracle_factory(t)
+        d1 = o1.alloc_derivs()
+        if t == T - 1:
+            d1["lfx"][:n] = d["lfx"][:n]; d1["lfxx"][:n * n] = d["lfxx"][:n * n]
+        else:
+            d1["lfx"][:n] = Vx_tr[(t + 1) * n:(t + 2) * n]; d1["lfxx"][:n * n] = Vxx_tr[(t + 1) * n * n:(t + 2) * n * n]
+        for key, per in (("lx", n), ("lu", m), ("lxx", n * n), ("lux", m * n), ("luu", m * m), ("f_val", nx), ("fx", n * n), ("fu", n * m),
+                         ("fxx", n ** 3), ("fux", n * m * n), ("fuu", n * m * m)):
+            if d[key].size >= (t + 1) * per:
+                d1[key][:per] = d[key][t * per:(t + 1) * per]
+        for key, per in (("eq_val", 1), ("eq_x", n), ("eq_u", m), ("eq_xx", n * n), ("eq_ux", m * n), ("eq_uu", m * m)):
+            if e and d[key].size >= (E0 + e) * per:
+                d1[key][:e * per] = d[key][E0 * per:(E0 + e) * per]
+        m1 = o1.alloc_affine(e)
+        m1["origin"][:] = mults["origin"][t * nx:(t + 1) * nx]
+        if e:
+            m1["val"][:e] = mults["val"][E0:E0 + e]
+            m1["jac"][:e * n] = mults["jac"][E0 * n:(E0 + e) * n]
+        ref = o1.backward(d1, np.concatenate([xs[t * nx:(t + 1) * nx], xs[(t + 1) * nx:(t + 2) * nx]]), m1, reg, mu)
+        assert ref["restarts"] == 0, (t, ref["restarts"])
+        worst = max(worst, rel_err(k_dev[t * m:(t + 1) * m], ref["fb"]["val"][:m]), rel_err(K_dev[t * m * n:(t + 1) * m * n], ref["fb"]["jac"][:m * n]),
+                    rel_err(Vx_tr[t * n:(t + 1) * n], ref["Vx"][:n]), rel_err(Vxx_tr[t * n * n:(t + 1) * n * n], ref["Vxx"][:n * n]))
+    return worst
