@@ -195,7 +195,6 @@ extern "C" int ddp_hip_create(const ddp_hip_problem* prob, int device, uint32_t 
   if (prob->T < 1 || prob->batch < 1 || mo.nv < 1 || mo.nv > DDP_MAXJ) return DDP_HIP_E_ARG;
   if (mo.kind != DDP_HIP_MODEL_PENDULUM && mo.kind != DDP_HIP_MODEL_TREE) return DDP_HIP_E_ARG;
   if (mo.kind == DDP_HIP_MODEL_PENDULUM && mo.nv != 1) return DDP_HIP_E_ARG;
-  if (mo.kind == DDP_HIP_MODEL_TREE && !prob->first_order_fd) return DDP_HIP_E_UNSUPPORTED;  // no analytic ABA derivatives yet
   if (prob->fd_mode < 0 || prob->fd_mode > 2) return DDP_HIP_E_ARG;
   if (prob->eq_kind != DDP_HIP_EQ_NONE && (!prob->ne || prob->eq_advance < 0 || prob->eq_advance > 4)) return DDP_HIP_E_ARG;
   if (prob->eq_kind == DDP_HIP_EQ_FRAME && (mo.kind != DDP_HIP_MODEL_TREE || prob->frame_joint < 0 || prob->frame_joint >= mo.nv))

@@ -111,6 +111,9 @@ struct ddp_hip_ctx {
   double* lin_qws2 = nullptr;  // second workspace + stream + events: the two configuration-level kernels of consecutive slices overlap
   hipStream_t lin_stream2 = nullptr;
   hipEvent_t lin_ev_up[2] = {nullptr, nullptr}, lin_ev_dn[2] = {nullptr, nullptr};
+  double* ana_T = nullptr;     // analytic-derivative workspace (lin_analytic.hip): T = [dtau/dq | dtau/dv] per evaluation of a slice
+  double* ana_M = nullptr;     // ... and M / M^-1 per configuration of a slice
+  int64_t ana_nbt = 0;         // (instance, t) pairs per slice
   int lin_static = 0;          // id of the compiled-in topology the model's tree matches (lin_static.hip), 0 = none
 
   // per-instance activity (ddp_hip_set_active): an inactive instance is frozen -- the sweeps skip it and swap_traj

@@ -16,6 +16,7 @@
 #include "internal.h"
 #include "lin_common.h"
 #include "rbd.h"
+#include "rbd_deriv.h"
 
 namespace {
 
@@ -65,7 +66,7 @@ __global__ void lin_base_kernel(LinParams p) {
   load_xu<NJ>(p, b, t, x, u);
   rbd::eval_f<NJ>(m, x, u, f);
   for (int i = 0; i < nx; ++i) p.f_val[gid * nx + i] = f[i];
-  if (!m.first_order_fd) {
+  if (!m.first_order_fd && m.kind == DDP_HIP_MODEL_PENDULUM) {
     double* fx = p.fx + gid * 4;
     double* fu = p.fu + gid * 2;
     const double aq = -9.81 / m.length * cos(x[0]);
@@ -323,6 +324,11 @@ __global__ __launch_bounds__(LBS, (PAIRS == 1 || PAIRS == 0 ? 4 : 5)) void lin_o
 template <int NJ>
 __device__ void first_order_f(const DevModel& m, const double* x, const double* u, double* fx, double* fu, double* f) {
   const int nv = m.nv, n = 2 * nv, mm = nv;
+  if (!m.first_order_fd && m.kind == DDP_HIP_MODEL_TREE) {
+    // analytic, as the reference: d_dynamics_aba (problem.hpp:495)
+    if constexpr (NJ <= 6) rbdd::first_order_analytic_lane<NJ>(m, x, u, fx, fu, f);
+    return;
+  }
   rbd::eval_f<NJ>(m, x, u, f);
   if (!m.first_order_fd) {
     const double aq = -9.81 / m.length * cos(x[0]);
@@ -340,6 +346,21 @@ __device__ void first_order_f(const DevModel& m, const double* x, const double* 
     double* col = j < n ? fx + j * n : fu + (j - n) * n;
     for (int k = 0; k < n; ++k) col[k] = (fp[k] - f[k]) / eps;
   }
+}
+
+// analytic first order of a small tree model (nv <= 6), one lane per (instance, t)
+template <int NJ>
+__global__ void lin_first_analytic_small_kernel(LinParams p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t T = p.d.T;
+  if (gid >= p.d.batch * T) return;
+  const int b = (int)(gid / T);
+  const int64_t t = gid % T;
+  const DevModel& m = *p.model;
+  const int n = 2 * m.nv, mm = m.nv;
+  double x[2 * NJ], u[NJ], f[2 * NJ];
+  load_xu<NJ>(p, b, t, x, u);
+  first_order_f<NJ>(m, x, u, p.fx + gid * n * n, p.fu + gid * n * mm, f);     // f_val itself is lin_base_kernel's (same arithmetic)
 }
 
 // constraint value through the advance chain (problem.hpp:563-567)
@@ -718,7 +739,10 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
   if (stages & DDP_HIP_LIN_FIRST) {
     prof_begin(ctx, DDP_HIP_K_LIN_FIRST);
     hipLaunchKernelGGL((lin_base_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
-    if (ctx->model_h.first_order_fd) {
+    if (!ctx->model_h.first_order_fd && ctx->model_h.kind == DDP_HIP_MODEL_TREE) {
+      if constexpr (small) hipLaunchKernelGGL((lin_first_analytic_small_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
+      else { const int rc_ = lin_analytic_launch(ctx, p, 0); if (rc_ != DDP_HIP_OK) return rc_; }
+    } else if (ctx->model_h.first_order_fd) {
       if (ctx->lin_static && p.qcache && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); { const int rc_ = lin_static_launch(ctx, p, 0); if (rc_ != DDP_HIP_OK) return rc_; } }
       else hipLaunchKernelGGL((lin_first_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
     }
@@ -745,10 +769,9 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 0>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p);
       }
     } else if (fd_mode == 1) {
-      if constexpr (small) {
-        if (ctx->model_h.first_order_fd) return DDP_HIP_E_UNSUPPORTED;  // FD of FD jacobians is numerically void
-        hipLaunchKernelGGL((second_m1_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
-      } else return DDP_HIP_E_UNSUPPORTED;
+      if (ctx->model_h.first_order_fd) return DDP_HIP_E_UNSUPPORTED;  // forward differences of FD jacobians are numerically void
+      if constexpr (small) hipLaunchKernelGGL((second_m1_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
+      else { const int rc_ = lin_analytic_launch(ctx, p, 1); if (rc_ != DDP_HIP_OK) return rc_; }
     } else {
       // fd_mode 0: Gauss-Newton variant, tensors are zero
       HIP_TRY(hipMemsetAsync(p.fxx, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_FXX].size * d.batch), ctx->stream));
@@ -829,6 +852,13 @@ int lin_setup(ddp_hip_ctx* ctx) {
       }
     }
   }
+  {
+    // analytic first order on large trees: its own kernels and workspace; the constraint chain of large models still
+    // differences f at the look-ahead states, which would mix the two kinds of jacobian: refused
+    if (tree && !ctx->model_h.first_order_fd && ctx->d.nv > 6 && ctx->d.Etot > 0) return DDP_HIP_E_UNSUPPORTED;
+    const int rc_ = lin_analytic_setup(ctx);
+    if (rc_ != DDP_HIP_OK) return rc_;
+  }
   // look-ahead states / jacobians of the constraint chain on large models
   if (ctx->d.Etot > 0 && ctx->d.nv > 6) {
     const Dims& d = ctx->d;
@@ -839,6 +869,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
   return DDP_HIP_OK;
 }
 void lin_teardown(ddp_hip_ctx* ctx) {
+  lin_analytic_teardown(ctx);
   for (int k = 0; k < 2; ++k) {
     if (ctx->lin_ev_up[k]) (void)hipEventDestroy(ctx->lin_ev_up[k]);
     if (ctx->lin_ev_dn[k]) (void)hipEventDestroy(ctx->lin_ev_dn[k]);

@@ -27,3 +27,9 @@ constexpr int LBS = 64;
 int lin_static_supported(const DevModel& m);   // 0: none, else the id of the compiled-in topology
 int lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level);   // DDP_HIP_OK or an error code
 int64_t lin_static_ws_per_bt(const DevModel& m);
+
+// analytic first order / mode-1 second order of large tree models (lin_analytic.hip): stage 0 = f_x, f_u at the
+// trajectory points (problem.hpp:463-503), stage 1 = forward differences of those jacobians (problem.hpp:67-150)
+int lin_analytic_setup(ddp_hip_ctx* ctx);
+void lin_analytic_teardown(ddp_hip_ctx* ctx);
+int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage);

@@ -76,6 +76,8 @@ def lib(path=None):
     L.orc_aba.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp]
     L.orc_rnea.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp]
     L.orc_crba.argtypes = [C.POINTER(OrcModel), _dp, _dp]
+    L.orc_rnea_derivatives.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp, _dp, _dp]
+    L.orc_aba_derivatives.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_frame_position.argtypes = [C.POINTER(OrcModel), C.c_int32, _dp, _dp, _dp]
     L.orc_frame_jacobian.argtypes = [C.POINTER(OrcModel), C.c_int32, _dp, _dp, C.c_int, _dp]
     L.orc_eval_f.argtypes = [C.POINTER(OrcProblem), _dp, _dp, _dp]
@@ -176,6 +178,22 @@ class Oracle:
         out = np.zeros((self.nv, self.nv))
         self.L.orc_crba(C.byref(self.model), _p(q), _p(out))
         return out.T.copy()  # column-major -> numpy
+
+    def rnea_derivatives(self, q, v, a):
+        """(dtau/dq, dtau/dv, M) of tau = RNEA(q, v, a), each nv x nv"""
+        q, v, a = _f64(q), _f64(v), _f64(a)
+        n = self.nv
+        dq, dv, M = np.zeros(n * n), np.zeros(n * n), np.zeros(n * n)
+        self.L.orc_rnea_derivatives(C.byref(self.model), _p(q), _p(v), _p(a), _p(dq), _p(dv), _p(M))
+        return dq.reshape(n, n).T.copy(), dv.reshape(n, n).T.copy(), M.reshape(n, n).T.copy()
+
+    def aba_derivatives(self, q, v, tau):
+        """(dqdd/dq, dqdd/dv, dqdd/dtau) of qdd = ABA(q, v, tau), each nv x nv (d_dynamics_aba, pinocchio_model.ipp:359-400)"""
+        q, v, tau = _f64(q), _f64(v), _f64(tau)
+        n = self.nv
+        dq, dv, dt = np.zeros(n * n), np.zeros(n * n), np.zeros(n * n)
+        self.L.orc_aba_derivatives(C.byref(self.model), _p(q), _p(v), _p(tau), _p(dq), _p(dv), _p(dt))
+        return dq.reshape(n, n).T.copy(), dv.reshape(n, n).T.copy(), dt.reshape(n, n).T.copy()
 
     def frame_position(self, joint, off, q):
         off, q = _f64(off), _f64(q)

@@ -429,6 +429,167 @@ void orc_frame_jacobian(const orc_model* m, int32_t joint, const double* off, co
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* analytic derivatives of the forward dynamics (what the reference delegates to Pinocchio's      */
+/* computeABADerivatives, pinocchio_model.ipp:390-399; Pinocchio is absent, version unpinned).    */
+/* Restated from the published recursion (Carpentier & Mansard, "Analytical derivatives of rigid   */
+/* body dynamics algorithms", RSS 2018): d qdd/dq = -M^-1 d tau/dq, d qdd/dv = -M^-1 d tau/dv,     */
+/* d qdd/d tau = M^-1, with the partials of the inverse dynamics tau = RNEA(q, v, qdd) formed in   */
+/* WORLD coordinates.  With J_i the world-frame axis of joint i, ov / oa the world-frame body      */
+/* velocities / accelerations (gravity folded into a_0), I_k the world-frame body inertias,        */
+/* h = I ov, of = I oa + ov x* h, B_k x = I_k (x x ov_k) + x x* h_k + ov_k x* (I_k x), and composite  */
+/* (subtree) sums Ic, Bc, ofc:                                                                       */
+/*   u_j = J_j x ov_j,   g_j = u_j x ov_j - J_j x oa_j                                              */
+/*   i in path(j):          d tau_i/dq_j = J_i . (J_j x* ofc_j - Bc_j u_j + Ic_j g_j)               */
+/*                          d tau_i/dv_j = J_i . (Bc_j J_j - 2 Ic_j u_j),   M_ij = J_i . Ic_j J_j   */
+/*   j proper ancestor of i: d tau_i/dq_j = -(Bc_i^T J_i) . u_j + (Ic_i J_i) . g_j                  */
+/*                          d tau_i/dv_j =  (Bc_i^T J_i) . J_j - 2 (Ic_i J_i) . u_j                 */
+/* Pinned by central differences of orc_rnea / orc_aba and by an mpmath restatement at 50 digits    */
+/* (tests/test_oracle_pinning.py); the reference holds no numbers for it: parity unpinned.          */
+/* ------------------------------------------------------------------------------------------ */
+static void forward_kinematics(const orc_model* m, const double* q, double* oR, double* op);
+
+void orc_rnea_derivatives(const orc_model* m, const double* q, const double* v, const double* a,
+                          double* dtau_dq, double* dtau_dv, double* M) {
+  int N = m->nv;
+  if (m->kind == ORC_MODEL_PENDULUM) {       /* tau = m (a + g/l sin q): pendulum_model.hpp:105-130 */
+    dtau_dq[0] = m->mass * 9.81 / m->length * cos(q[0]);
+    dtau_dv[0] = 0.0;
+    M[0] = m->mass;
+    return;
+  }
+  double* oR = dalloc(9 * N); double* op = dalloc(3 * N);
+  double* J = dalloc(6 * N); double* ov = dalloc(6 * N); double* oa = dalloc(6 * N);
+  double* Ic = dalloc(36 * N); double* Bc = dalloc(36 * N); double* ofc = dalloc(6 * N);
+  double* y = dalloc(6 * N); double* z = dalloc(6 * N); double* u = dalloc(6 * N); double* g = dalloc(6 * N);
+  double* Fq = dalloc(6 * N); double* Fv = dalloc(6 * N);
+  forward_kinematics(m, q, oR, op);
+  for (int i = 0; i < N; ++i) {
+    double aw[3], t[3], t6[6];
+    mat3_vec(oR + 9 * i, m->axis + 3 * i, aw);
+    double* Ji = J + 6 * i;
+    if (m->jtype[i] == ORC_JOINT_REVOLUTE) {
+      cross3(op + 3 * i, aw, t);               /* velocity of the body point at the world origin */
+      Ji[0] = aw[0]; Ji[1] = aw[1]; Ji[2] = aw[2]; Ji[3] = t[0]; Ji[4] = t[1]; Ji[5] = t[2];
+    } else {
+      Ji[0] = Ji[1] = Ji[2] = 0.0; Ji[3] = aw[0]; Ji[4] = aw[1]; Ji[5] = aw[2];
+    }
+    int par = m->parent[i];
+    double a0[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
+    const double* vp = par >= 0 ? ov + 6 * par : NULL;
+    const double* ap = par >= 0 ? oa + 6 * par : a0;
+    double vJ[6];
+    for (int k = 0; k < 6; ++k) vJ[k] = Ji[k] * v[i];
+    for (int k = 0; k < 6; ++k) ov[6 * i + k] = (vp ? vp[k] : 0.0) + vJ[k];
+    crm(ov + 6 * i, vJ, t6);                   /* ov_i x J_i qd_i (= ov_parent x J_i qd_i) */
+    for (int k = 0; k < 6; ++k) oa[6 * i + k] = ap[k] + Ji[k] * a[i] + t6[k];
+    /* world-frame inertia of body i about the world origin */
+    double cw[3], Icw[9], Rt[9], T1[9], cx[9], cxT[9], cc[9];
+    mat3_vec(oR + 9 * i, m->com + 3 * i, cw);
+    for (int k = 0; k < 3; ++k) cw[k] += op[3 * i + k];
+    for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) Rt[3 * k + l] = oR[9 * i + 3 * l + k];
+    mat3_mul(oR + 9 * i, m->Ic + 9 * i, T1);
+    mat3_mul(T1, Rt, Icw);
+    skew(cw, cx);
+    for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) cxT[3 * k + l] = cx[3 * l + k];
+    mat3_mul(cx, cxT, cc);
+    double* I6 = Ic + 36 * i;
+    double mass = m->mass_j[i];
+    memset(I6, 0, 36 * sizeof(double));
+    for (int k = 0; k < 3; ++k)
+      for (int l = 0; l < 3; ++l) {
+        I6[6 * k + l] = Icw[3 * k + l] + mass * cc[3 * k + l];
+        I6[6 * k + l + 3] = mass * cx[3 * k + l];
+        I6[6 * (k + 3) + l] = mass * cxT[3 * k + l];
+      }
+    I6[21] = I6[28] = I6[35] = mass;
+    double h[6], Ioa[6], vxh[6];
+    mat6_vec(I6, ov + 6 * i, h);
+    mat6_vec(I6, oa + 6 * i, Ioa);
+    crf(ov + 6 * i, h, vxh);
+    for (int k = 0; k < 6; ++k) ofc[6 * i + k] = Ioa[k] + vxh[k];
+    /* B x = I (x x ov) + x x* h + ov x* (I x), column by column */
+    double* B = Bc + 36 * i;
+    for (int c = 0; c < 6; ++c) {
+      double e[6] = {0, 0, 0, 0, 0, 0}, exv[6], t1[6], t2[6], Icol[6], t3[6];
+      e[c] = 1.0;
+      crm(e, ov + 6 * i, exv);
+      mat6_vec(I6, exv, t1);
+      crf(e, h, t2);
+      for (int k = 0; k < 6; ++k) Icol[k] = I6[6 * k + c];
+      crf(ov + 6 * i, Icol, t3);
+      for (int k = 0; k < 6; ++k) B[6 * k + c] = t1[k] + t2[k] + t3[k];
+    }
+  }
+  for (int i = N - 1; i >= 0; --i) {           /* composite (subtree) sums */
+    int par = m->parent[i];
+    if (par < 0) continue;
+    for (int k = 0; k < 36; ++k) { Ic[36 * par + k] += Ic[36 * i + k]; Bc[36 * par + k] += Bc[36 * i + k]; }
+    for (int k = 0; k < 6; ++k) ofc[6 * par + k] += ofc[6 * i + k];
+  }
+  for (int i = 0; i < N; ++i) {
+    const double* Ji = J + 6 * i;
+    double t1[6], t2[6], t3[6];
+    mat6_vec(Ic + 36 * i, Ji, y + 6 * i);
+    mat6_tvec(Bc + 36 * i, Ji, z + 6 * i);
+    crm(Ji, ov + 6 * i, u + 6 * i);
+    crm(u + 6 * i, ov + 6 * i, t1);
+    crm(Ji, oa + 6 * i, t2);
+    for (int k = 0; k < 6; ++k) g[6 * i + k] = t1[k] - t2[k];
+    crf(Ji, ofc + 6 * i, t1);
+    mat6_vec(Bc + 36 * i, u + 6 * i, t2);
+    mat6_vec(Ic + 36 * i, g + 6 * i, t3);
+    for (int k = 0; k < 6; ++k) Fq[6 * i + k] = t1[k] - t2[k] + t3[k];
+    mat6_vec(Bc + 36 * i, Ji, t1);
+    mat6_vec(Ic + 36 * i, u + 6 * i, t2);
+    for (int k = 0; k < 6; ++k) Fv[6 * i + k] = t1[k] - 2.0 * t2[k];
+  }
+  memset(dtau_dq, 0, sizeof(double) * (size_t)N * N);
+  memset(dtau_dv, 0, sizeof(double) * (size_t)N * N);
+  memset(M, 0, sizeof(double) * (size_t)N * N);
+  for (int j = 0; j < N; ++j) {
+    for (int i = j; i >= 0; i = m->parent[i]) {            /* i in path(j) */
+      double sq = 0, sv = 0, sm = 0;
+      for (int k = 0; k < 6; ++k) { sq += J[6 * i + k] * Fq[6 * j + k]; sv += J[6 * i + k] * Fv[6 * j + k]; sm += J[6 * i + k] * y[6 * j + k]; }
+      dtau_dq[i + (int64_t)j * N] = sq;
+      dtau_dv[i + (int64_t)j * N] = sv;
+      M[i + (int64_t)j * N] = sm;
+      M[j + (int64_t)i * N] = sm;
+    }
+    for (int a_ = m->parent[j]; a_ >= 0; a_ = m->parent[a_]) {   /* a_ proper ancestor of j: row j, column a_ */
+      double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+      for (int k = 0; k < 6; ++k) {
+        s1 += z[6 * j + k] * u[6 * a_ + k]; s2 += y[6 * j + k] * g[6 * a_ + k];
+        s3 += z[6 * j + k] * J[6 * a_ + k]; s4 += y[6 * j + k] * u[6 * a_ + k];
+      }
+      dtau_dq[j + (int64_t)a_ * N] = -s1 + s2;
+      dtau_dv[j + (int64_t)a_ * N] = s3 - 2.0 * s4;
+    }
+  }
+  free(oR); free(op); free(J); free(ov); free(oa); free(Ic); free(Bc); free(ofc);
+  free(y); free(z); free(u); free(g); free(Fq); free(Fv);
+}
+
+/* model_t::d_dynamics_aba, pinocchio_model.ipp:359-400: partials of qdd = ABA(q, v, tau), nv x nv column-major each */
+void orc_aba_derivatives(const orc_model* m, const double* q, const double* v, const double* tau,
+                         double* dq, double* dv, double* dtau) {
+  int N = m->nv;
+  double* a = dalloc(N);
+  double* tq = dalloc((int64_t)N * N); double* tv = dalloc((int64_t)N * N); double* M = dalloc((int64_t)N * N);
+  orc_aba(m, q, v, tau, a);
+  orc_rnea_derivatives(m, q, v, a, tq, tv, M);
+  /* M = L L^T; columns of M^-1, -M^-1 dtau/dq, -M^-1 dtau/dv by substitution */
+  int64_t bad = llt_lower(N, M, N);
+  (void)bad;                                   /* a joint-space inertia matrix is positive definite */
+  memset(dtau, 0, sizeof(double) * (size_t)N * N);
+  for (int i = 0; i < N; ++i) dtau[i + (int64_t)i * N] = 1.0;
+  llt_solve(N, M, N, N, dtau, N);
+  for (int64_t k = 0; k < (int64_t)N * N; ++k) { dq[k] = -tq[k]; dv[k] = -tv[k]; }
+  llt_solve(N, M, N, N, dq, N);
+  llt_solve(N, M, N, N, dv, N);
+  free(a); free(tq); free(tv); free(M);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* dynamics_t : problem.hpp:343-525                                                            */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -446,17 +607,17 @@ void orc_eval_f(const orc_problem* p, const double* x, const double* u, double* 
 }
 
 /* dynamics_t::first_order_deriv, problem.hpp:463-503.
- *  - pendulum: analytic, exactly as the reference (pendulum_model.hpp:116-130);
- *  - tree models: the reference calls Pinocchio's computeABADerivatives (absent here); the build's
- *    north star asks for forward finite differences instead: column j is
+ *  - first_order_fd = 0: analytic, as the reference -- the pendulum's closed form (pendulum_model.hpp:116-130) or, for
+ *    tree models, orc_aba_derivatives above (the reference calls Pinocchio's computeABADerivatives);
+ *  - first_order_fd = 1: the build's north star asks for forward finite differences: column j is
  *    difference_out(f(x,u), f(x (+) eps e_j, u)) / eps, eps = sqrt(DBL_EPSILON), perturbing with
  *    integrate_x / integrate_u exactly like problem.hpp:105-126 does for the second order. */
 void orc_first_order_f(const orc_problem* p, const double* x, const double* u, double* fx, double* fu, double* f) {
   int nv = p->model.nv;
   int64_t n = 2 * nv, m = nv;
   orc_eval_f(p, x, u, f);
-  if (!p->first_order_fd) {
-    /* only the pendulum has closed-form partials */
+  if (!p->first_order_fd && p->model.kind == ORC_MODEL_PENDULUM) {
+    /* closed-form partials (pendulum_model.hpp:116-130) */
     double aq = -9.81 / p->model.length * cos(x[0]);
     double av = 0.0, at = 1.0 / p->model.mass;
     fx[0 + 0 * 2] = 1.0;            /* d_integrate_dq */
@@ -465,6 +626,25 @@ void orc_first_order_f(const orc_problem* p, const double* x, const double* u, d
     fx[1 + 1 * 2] = av * p->dt + 1.0;
     fu[0] = 0.0;
     fu[1] = at * p->dt;
+    return;
+  }
+  if (!p->first_order_fd) {
+    /* problem.hpp:463-503 with d_dynamics_aba (:495): fx = [dInt_dq, dt dInt_dv; dt da/dq, I + dt da/dv], fu = [0; dt da/dtau];
+     * on a vector space d_integrate_dq = d_integrate_dv = I (pendulum_model.hpp:64-84 does the same) */
+    double* dq = dalloc((int64_t)nv * nv); double* dv = dalloc((int64_t)nv * nv); double* dt_ = dalloc((int64_t)nv * nv);
+    orc_aba_derivatives(&p->model, x, x + nv, u, dq, dv, dt_);
+    memset(fx, 0, sizeof(double) * (size_t)(n * n));
+    memset(fu, 0, sizeof(double) * (size_t)(n * m));
+    for (int j = 0; j < nv; ++j) {
+      fx[j + (int64_t)j * n] = 1.0;                           /* top left */
+      fx[j + (int64_t)(nv + j) * n] = 1.0 * p->dt;            /* top right: d_integrate_dv * dt (:489-490) */
+      for (int i = 0; i < nv; ++i) {
+        fx[(nv + i) + (int64_t)j * n] = dq[i + (int64_t)j * nv] * p->dt;                                  /* :499 */
+        fx[(nv + i) + (int64_t)(nv + j) * n] = dv[i + (int64_t)j * nv] * p->dt + (i == j ? 1.0 : 0.0);    /* :500-501 */
+        fu[(nv + i) + (int64_t)j * n] = dt_[i + (int64_t)j * nv] * p->dt;                                 /* :502 */
+      }
+    }
+    free(dq); free(dv); free(dt_);
     return;
   }
   double eps = sqrt(DBL_EPSILON);

@@ -64,7 +64,7 @@ typedef struct orc_problem {
   const double* eq_target; /* flat, concatenated over t: ne[t] doubles each */
   int32_t frame_joint;     /* ORC_EQ_FRAME: joint the frame is attached to */
   double frame_off[3];     /* frame origin in that joint's frame */
-  int32_t first_order_fd;  /* 0: analytic first_order_deriv (pendulum only); 1: forward FD, eps = sqrt(eps_mach) */
+  int32_t first_order_fd;  /* 0: analytic first_order_deriv (problem.hpp:463-503); 1: forward FD, eps = sqrt(eps_mach) */
   int32_t fd_mode;         /* second order: 0 none (zero tensors), 1 (problem.hpp:67-150), 2 (problem.hpp:152-298) */
 } orc_problem;
 
@@ -91,6 +91,12 @@ int64_t orc_ne_total(const orc_problem* p);
 void orc_aba(const orc_model* m, const double* q, const double* v, const double* tau, double* qdd);
 void orc_rnea(const orc_model* m, const double* q, const double* v, const double* a, double* tau);
 void orc_crba(const orc_model* m, const double* q, double* M /* nv x nv col-major */);
+/* partials of tau = RNEA(q, v, a) wrt q and v, and the joint-space inertia matrix (nv x nv col-major each) */
+void orc_rnea_derivatives(const orc_model* m, const double* q, const double* v, const double* a,
+                          double* dtau_dq, double* dtau_dv, double* M);
+/* model_t::d_dynamics_aba (pinocchio_model.ipp:359-400): partials of qdd = ABA(q, v, tau) wrt q, v, tau */
+void orc_aba_derivatives(const orc_model* m, const double* q, const double* v, const double* tau,
+                         double* dq, double* dv, double* dtau);
 void orc_frame_position(const orc_model* m, int32_t joint, const double* off, const double* q, double* p3);
 /* top three rows of the WORLD-frame jacobian as the reference takes them
  * (pinocchio_model.ipp:458-461); world_aligned != 0 gives d(position)/dq instead */

@@ -256,3 +256,94 @@ def backward_mpmath(T, n, m, nx, ne, d, xs, mults, reg, mu, dps=50):
         Vxs[t] = [float(Vx[i]) for i in range(n)]
         Vxxs[t] = [[float(Vxx[i, j]) for j in range(n)] for i in range(n)]
     return dict(k=ks, K=Ks, Vx=Vxs, Vxx=Vxxs)
+
+
+# ---------------------------------------------------------------------------------------------
+# forward dynamics in mpmath (Featherstone RBDA Table 7.1, dense 6x6 Pluecker transforms): pins the analytic
+# derivatives of oracle/ddp_oracle.c (orc_aba_derivatives) well below double precision -- central differences at
+# 50 digits with a step of 1e-20 have a truncation error of ~1e-40
+# ---------------------------------------------------------------------------------------------
+def aba_mpmath(model, q, v, tau, dps=50):
+    """qdd = ABA(q, v, tau) for a tree of 1-DoF joints; `model` has the attributes of capi.BuiltinModel"""
+    import mpmath as mp
+    mp.mp.dps = dps
+    N = int(model.nv)
+    f = mp.mpf
+
+    def M(rows):
+        return mp.matrix([[f(x) for x in r] for r in rows])
+
+    def skew(a):
+        return mp.matrix([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+
+    def crm(vv):
+        w, l = skew(vv[0:3]), skew(vv[3:6])
+        out = mp.zeros(6, 6)
+        out[0:3, 0:3] = w; out[3:6, 0:3] = l; out[3:6, 3:6] = w
+        return out
+
+    X, S, vel, c, IA, pA = [None] * N, [None] * N, [None] * N, [None] * N, [None] * N, [None] * N
+    for i in range(N):
+        a = mp.matrix([f(x) for x in model.axis[i]])
+        Rp = M(model.Rp[i])
+        pp = mp.matrix([f(x) for x in model.pp[i]])
+        if int(model.jtype[i]) == 0:
+            K = skew(a)
+            RJ = mp.eye(3) + mp.sin(f(q[i])) * K + (1 - mp.cos(f(q[i]))) * (K * K)
+            Rc, r = Rp * RJ, pp
+            S[i] = mp.matrix([a[0], a[1], a[2], 0, 0, 0])
+        else:
+            Rc, r = Rp, pp + Rp * (a * f(q[i]))
+            S[i] = mp.matrix([0, 0, 0, a[0], a[1], a[2]])
+        E = Rc.T
+        Xi = mp.zeros(6, 6)
+        Xi[0:3, 0:3] = E; Xi[3:6, 3:6] = E; Xi[3:6, 0:3] = -(E * skew(r))
+        X[i] = Xi
+        vJ = S[i] * f(v[i])
+        par = int(model.parent[i])
+        vel[i] = (X[i] * vel[par] if par >= 0 else mp.zeros(6, 1)) + vJ
+        c[i] = crm(vel[i]) * vJ
+        com = mp.matrix([f(x) for x in model.com[i]])
+        cx = skew(com)
+        mass = f(model.mass_j[i])
+        I6 = mp.zeros(6, 6)
+        I6[0:3, 0:3] = M(model.Ic[i]) + mass * (cx * cx.T); I6[0:3, 3:6] = mass * cx; I6[3:6, 0:3] = mass * cx.T
+        I6[3:6, 3:6] = mass * mp.eye(3)
+        IA[i] = I6
+        pA[i] = -(crm(vel[i]).T) * (I6 * vel[i])          # v x* (I v), crf(v) = -crm(v)^T
+    U, D, u = [None] * N, [None] * N, [None] * N
+    for i in range(N - 1, -1, -1):
+        U[i] = IA[i] * S[i]
+        D[i] = (S[i].T * U[i])[0]
+        u[i] = f(tau[i]) - (S[i].T * pA[i])[0]
+        par = int(model.parent[i])
+        if par >= 0:
+            Ia = IA[i] - U[i] * U[i].T / D[i]
+            pa = pA[i] + Ia * c[i] + U[i] * (u[i] / D[i])
+            IA[par] = IA[par] + X[i].T * Ia * X[i]
+            pA[par] = pA[par] + X[i].T * pa
+    g = [f(x) for x in model.gravity]
+    a0 = mp.matrix([0, 0, 0, -g[0], -g[1], -g[2]])
+    acc, qdd = [None] * N, [None] * N
+    for i in range(N):
+        par = int(model.parent[i])
+        ap = X[i] * (acc[par] if par >= 0 else a0) + c[i]
+        qdd[i] = (u[i] - (U[i].T * ap)[0]) / D[i]
+        acc[i] = ap + S[i] * qdd[i]
+    return qdd
+
+
+def aba_derivatives_mpmath(model, q, v, tau, cols, dps=50, h="1e-20"):
+    """columns `cols` (each (which, j), which in 'q', 'v', 't') of the partials of ABA by central differences in mpmath"""
+    import mpmath as mp
+    mp.mp.dps = dps
+    hh = mp.mpf(h)
+    out = {}
+    for which, j in cols:
+        args = {"q": [mp.mpf(float(x)) for x in q], "v": [mp.mpf(float(x)) for x in v], "t": [mp.mpf(float(x)) for x in tau]}
+        args[which][j] += hh
+        fp = aba_mpmath(model, args["q"], args["v"], args["t"], dps)
+        args[which][j] -= 2 * hh
+        fm = aba_mpmath(model, args["q"], args["v"], args["t"], dps)
+        out[which, j] = np.array([float((a - b) / (2 * hh)) for a, b in zip(fp, fm)])
+    return out

@@ -6,7 +6,8 @@ from ddp_pinocchio_amd import capi
 from oracle.binding import Oracle
 
 
-def make(name, T, batch=1, fd_mode=2, seed=1):
+def make(name, T, batch=1, fd_mode=2, seed=1, first_order_fd=None, target=None):
+    """target: overrides the constraint target (per-row value(s), repeated over t); first_order_fd: 0 analytic, 1 FD"""
     if name == "pendulum":        # test/pendulum_ddp.cpp: target q = 3.14 at the unshifted time `horizon`
         model = capi.BuiltinModel(capi.BUILTIN_PENDULUM)
         ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 1
@@ -34,9 +35,12 @@ def make(name, T, batch=1, fd_mode=2, seed=1):
         kw = dict(eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))
     else:
         raise ValueError(name)
-    spec = capi.ProblemSpec(model, T, dt=0.01, c=1.0, batch=batch, fd_mode=fd_mode, **kw)
+    if target is not None:
+        e_rows = int(kw["ne"].max())
+        kw["eq_target"] = np.tile(np.broadcast_to(np.asarray(target, dtype=float), (e_rows,)), int((kw["ne"] > 0).sum()))
+    spec = capi.ProblemSpec(model, T, dt=0.01, c=1.0, batch=batch, fd_mode=fd_mode, first_order_fd=first_order_fd, **kw)
     okw = dict(kw)
-    oracle = Oracle(model, T, dt=0.01, c=1.0, fd_mode=fd_mode, **okw)
+    oracle = Oracle(model, T, dt=0.01, c=1.0, fd_mode=fd_mode, first_order_fd=first_order_fd, **okw)
     return model, spec, oracle
 
 

@@ -1,0 +1,151 @@
+"""Analytic ABA derivatives on the device (reference: first_order_deriv problem.hpp:463-503 with
+model_t::d_dynamics_aba pinocchio_model.ipp:359-400) and FD mode 1 on tree models (problem.hpp:67-150: forward
+differences of the analytic jacobians -- what both reference UR5 drivers use, test/pinocchio_ddp.cpp:60).
+
+f_x / f_u are held to 1e-10 relative (no finite-difference noise any more: the two sides differ by the rounding of two
+independent restatements of the same recursion).  The mode-1 tensors are forward differences of those jacobians with
+eps = 1.5e-8: a few ulp of the jacobian entries over eps."""
+import numpy as np
+import pytest
+
+from problems import held_trajectory, initial_trajectory, make
+from synth import rel_err
+from test_dynamics_parity import DERIV_SEQS, TENSOR_SEQS, _upload_traj
+
+EPS, E1 = 2.220446049250313e-16, 1.4901161193847656e-08
+
+
+def _check_linearize(capi, name, T, traj, ulps=8, batch=1):
+    model, spec, o = make(name, T, fd_mode=1, first_order_fd=0, batch=batch)
+    x0, us, xs = traj(o, model)
+    d = o.compute_derivatives(xs, us)
+    with capi.Context(spec) as ctx:
+        assert ctx.info()["first_order"] == 2
+        for b in range(batch):
+            _upload_traj(ctx, xs, us, b)
+        ctx.linearize()
+        jscale = max(1.0, float(np.max(np.abs(d["fx"]))), float(np.max(np.abs(d["fu"]))))
+        # the entries of M^-1 (f_u = dt M^-1, d qdd/dx = -M^-1 d tau/dx) are only good to cond(M) ulps on either side, and the
+        # forward difference divides that by eps: the noise floor of mode 1 in double (the reference runs it in mpfr)
+        nv = model.nv
+        cond = max(float(np.linalg.cond(o.crba(xs[t * 2 * nv:t * 2 * nv + nv]))) for t in range(0, T, max(1, T // 8)))
+        for b in range(batch):
+            for key, seq in {**DERIV_SEQS, **TENSOR_SEQS}.items():
+                sz = ctx.seq_size(seq)
+                if not sz:
+                    continue
+                got = ctx.download(seq, b, 1)[0]
+                ref = d[key][:sz]
+                err, scale = float(np.max(np.abs(got - ref))), max(1.0, float(np.max(np.abs(ref))))
+                assert np.all(np.isfinite(got)), key
+                if key in ("lfx", "lfxx", "lx", "lu", "lxx", "lux", "luu"):
+                    assert err == 0.0, key
+                elif key in ("f_val", "eq_val"):
+                    assert err <= 1e-12 * scale, (key, err)
+                elif key in ("fx", "fu", "eq_x", "eq_u"):
+                    assert err <= 1e-10 * scale, (key, err, scale)                       # analytic: the north star's 1e-10
+                elif key in ("fxx", "fux", "fuu"):
+                    assert err <= ulps * EPS * cond * jscale / E1, (key, err, ulps * EPS * cond * jscale / E1)
+                else:                                                                   # eq tensors: two chained linearisations
+                    assert err <= 8 * ulps * EPS * cond * jscale * scale / E1, (key, err)
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("chain6", 10), ("chain6_frame", 10), ("chain6", 100)])
+def test_analytic_linearize_chain(gpu, name, T):
+    """the UR5-like chain in the derivative mode of the reference's own drivers: dy{model, 0.01, false}"""
+    _check_linearize(gpu, name, T, lambda o, model: held_trajectory(o, model, seed=3, u_sigma=0.05))
+
+
+@pytest.mark.gpu
+def test_mode1_structure_zero_blocks(gpu):
+    """M^-1 depends on q alone, so f_u is the same at (x, u), (x + eps e_v, u) and (x, u + eps e_u): the v-slabs of f_ux
+    and all of f_uu are exactly zero, as they are in the reference (fu_ - fu == 0 before the division by eps)"""
+    capi = gpu
+    T = 4
+    model, spec, o = make("chain6", T, fd_mode=1, first_order_fd=0)
+    x0, us, xs = held_trajectory(o, model, seed=4, u_sigma=0.05)
+    with capi.Context(spec) as ctx:
+        _upload_traj(ctx, xs, us)
+        ctx.linearize()
+        n, m, nv = o.n, o.m, model.nv
+        fuu = ctx.download("FUU", 0, 1)[0]
+        fux = ctx.download("FUX", 0, 1)[0].reshape(T, n, m, n)      # [t][k = x index][j][i]
+        assert np.all(fuu == 0.0)
+        assert np.all(fux[:, nv:, :, :] == 0.0) and np.any(fux[:, :nv, :, :] != 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fd_mode,tol", [(0, 1e-8), (1, 2e-2)])
+def test_analytic_whole_solve_chain(gpu, fd_mode, tol):
+    """test/pinocchio_ddp.cpp's configuration (UR5-like chain, config constraint every step, analytic first order) end to
+    end on a batch of two different instances, against each instance's own oracle solve.
+    fd_mode 0 (tensor-free): no finite difference anywhere -- the final trajectories agree to 1e-8 (round 1, FD jacobians:
+    1e-4).  fd_mode 1 (the driver's dy{model, 0.01, false}): the tensors are forward differences of jacobians that are good
+    to cond(M) ulps, i.e. they carry ~1e-3 relative noise in double on either side (the oracle run twice with its input
+    perturbed by 1e-13 moves its own answer by 1e-5); logs must agree, the trajectories to that noise."""
+    from ddp_pinocchio_amd import solver
+    capi = gpu
+    T, B, iters, thr, mu, w, n = 10, 2, 12, 1e-6, 1e4, 1e-1, 10.0
+    model, spec, o = make("chain6", T, batch=B, fd_mode=fd_mode, first_order_fd=0)
+    rng = np.random.default_rng(3)
+    seed = 0.01 * rng.normal(size=o.Etot * o.n)
+    inits, refs = [], []
+    for b, sig in enumerate((0.01, 0.02)):
+        us0 = sig * np.random.default_rng(40 + b).normal(size=T * model.nv)
+        xs0 = o.rollout(np.zeros(2 * model.nv), us0)
+        inits.append((xs0, us0))
+        refs.append(o.solve(xs0, us0, seed, max_iterations=iters, threshold=thr, mu=mu, reg=0.0, w=w, n=n))
+    with capi.Context(spec, flags=0 if fd_mode else capi.FLAG_NO_TENSORS) as ctx:
+        for b, (xs0, us0) in enumerate(inits):
+            ctx.upload("X", xs0, b, 1); ctx.upload("U", us0, b, 1); ctx.upload("X_NEW", xs0, b, 1); ctx.upload("U_NEW", us0, b, 1)
+            ctx.upload("MULT_ORIGIN", xs0[:T * o.nx], b, 1)
+            ctx.upload("MULT_VAL", np.zeros(o.Etot), b, 1)
+            ctx.upload("MULT_JAC", seed, b, 1)
+        log = solver.solve(ctx, iters, thr, mu, 0.0, w, n)
+        xs, us = ctx.download("X"), ctx.download("U")
+    for b in range(B):
+        xs_ref, us_ref, fb_ref, log_ref = refs[b]
+        assert int(log["iterations"][b]) == log_ref["iterations"] and bool(log["done"][b]) == bool(log_ref["result"] == 1)
+        assert log["mu"][b] == log_ref["mu"] and log["reg"][b] == log_ref["reg"]
+        assert float(np.max(np.abs(xs[b] - xs_ref))) < tol, (b, float(np.max(np.abs(xs[b] - xs_ref))))
+        assert float(np.max(np.abs(us[b] - us_ref))) < 100 * tol * max(1.0, float(np.max(np.abs(us_ref)))), b
+        assert abs(log["opt_constr"][b] - log_ref["opt_constr"]) <= 100 * tol * max(1.0, log_ref["opt_constr"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [3, 200])
+def test_analytic_linearize_talos(gpu, T):
+    """the Talos-like tree: wave-per-evaluation kernels (lin_analytic.hip).  T = 200 x 6 instances exercises the workspace
+    slices; the oracle is evaluated at picked (instance, t) pairs"""
+    capi = gpu
+    if T == 3:
+        _check_linearize(capi, "tree38", T, lambda o, model: held_trajectory(o, model, seed=9, u_sigma=0.3))
+        return
+    B = 6
+    model, spec, o = make("tree38", T, batch=B, fd_mode=1, first_order_fd=0)
+    trajs = [held_trajectory(o, model, seed=70 + b, u_sigma=0.3) for b in range(B)]
+    picks = [(0, 0), (0, 199), (2, 100), (5, 23), (5, 24), (5, 199)]
+    n, m, nx = o.n, o.m, o.nx
+    with capi.Context(spec) as ctx:
+        ctx.upload("X", np.stack([tr[2] for tr in trajs])); ctx.upload("U", np.stack([tr[1] for tr in trajs]))
+        ctx.linearize()
+        got = {(k, b): ctx.download(s, b, 1)[0] for b in sorted({b for b, _ in picks})
+               for k, s in (("f_val", "F_VAL"), ("fx", "FX"), ("fu", "FU"), ("fxx", "FXX"), ("fux", "FUX"), ("fuu", "FUU"))}
+    P = len(picks)
+    _, _, op = make("tree38", P, fd_mode=1, first_order_fd=0)
+    xs_p = np.zeros((P + 1) * nx); us_p = np.zeros(P * m)
+    for i, (b, t) in enumerate(picks):
+        xs_p[i * nx:(i + 1) * nx] = trajs[b][2][t * nx:(t + 1) * nx]
+        us_p[i * m:(i + 1) * m] = trajs[b][1][t * m:(t + 1) * m]
+    d = op.compute_derivatives(xs_p, us_p)
+    jscale = max(1.0, float(np.max(np.abs(d["fx"]))), float(np.max(np.abs(d["fu"]))))
+    cond = max(float(np.linalg.cond(op.crba(xs_p[i * nx:i * nx + model.nv]))) for i in range(P))
+    sizes = {"f_val": nx, "fx": n * n, "fu": n * m, "fxx": n ** 3, "fux": n * m * n, "fuu": n * m * m}
+    for i, (b, t) in enumerate(picks):
+        for key, sz in sizes.items():
+            a, r = got[key, b][t * sz:(t + 1) * sz], d[key][i * sz:(i + 1) * sz]
+            err, scale = float(np.max(np.abs(a - r))), max(1.0, float(np.max(np.abs(r))))
+            tol = 1e-12 * scale if key == "f_val" else (1e-10 * scale if key in ("fx", "fu") else 8 * EPS * cond * jscale / E1)
+            assert np.all(np.isfinite(a)) and err <= tol, (key, b, t, err, tol)

@@ -213,3 +213,69 @@ def test_pendulum_solve_approaches_target():
                                 w=1.0, n=10.0)
     assert abs(xs2[2 * T] - 3.14) < 0.05, log
     assert log["opt_constr"] < 0.05 and log["opt_obj"] < 1e-6
+
+
+@pytest.mark.parametrize("which,cols", [
+    (1, [(w, j) for w in "qvt" for j in range(6)]),                                   # chain6: every column
+    (2, [("q", 1), ("q", 4), ("q", 9), ("q", 30), ("v", 3), ("v", 17), ("v", 37), ("t", 0), ("t", 25)]),   # tree38: base, leg, arm, head
+])
+def test_analytic_aba_derivatives_vs_mpmath(which, cols):
+    """orc_aba_derivatives (the reference's d_dynamics_aba = Pinocchio's computeABADerivatives, absent here) against
+    central differences of an independent mpmath forward dynamics at 50 digits: pins the analytic partials to 1e-11"""
+    from ddp_pinocchio_amd import capi
+    bm = capi.BuiltinModel(which, 1)
+    o = Oracle(bm, 1)
+    rng = np.random.default_rng(7)
+    N = bm.nv
+    q, v, tau = rng.normal(size=N), rng.normal(size=N), 3.0 * rng.normal(size=N)
+    a_mp = np.array([float(x) for x in npo.aba_mpmath(bm, q, v, tau)])
+    assert np.max(np.abs(a_mp - o.aba(q, v, tau))) <= 1e-12 * max(1.0, np.max(np.abs(a_mp)))
+    aq, av, at = o.aba_derivatives(q, v, tau)
+    scale = {"q": np.max(np.abs(aq)), "v": np.max(np.abs(av)), "t": np.max(np.abs(at))}
+    ref = npo.aba_derivatives_mpmath(bm, q, v, tau, cols)
+    for (w, j), c in ref.items():
+        mine = {"q": aq, "v": av, "t": at}[w][:, j]
+        assert np.max(np.abs(mine - c)) <= 1e-11 * scale[w], (w, j, np.max(np.abs(mine - c)), scale[w])
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_analytic_first_order_vs_finite_differences(which):
+    """first_order_deriv (problem.hpp:463-503) analytic vs the north star's forward differences: FD noise level only"""
+    from ddp_pinocchio_amd import capi
+    bm = capi.BuiltinModel(which, 1)
+    oa = Oracle(bm, 1, first_order_fd=0)
+    of = Oracle(bm, 1, first_order_fd=1)
+    rng = np.random.default_rng(8)
+    x, u = 0.5 * rng.normal(size=2 * bm.nv), rng.normal(size=bm.nv)
+    fxa, fua, fa = oa.first_order_f(x, u)
+    fxf, fuf, ff = of.first_order_f(x, u)
+    assert np.array_equal(fa, ff)
+    assert np.max(np.abs(fxa - fxf)) <= 2e-6 * max(1.0, np.max(np.abs(fxa)))
+    assert np.max(np.abs(fua - fuf)) <= 2e-6 * max(1.0, np.max(np.abs(fua)))
+    n, nv = 2 * bm.nv, bm.nv
+    FX = fxa.reshape(n, n).T
+    assert np.array_equal(FX[:nv, :nv], np.eye(nv)) and np.array_equal(FX[:nv, nv:], 0.01 * np.eye(nv))   # dInt_dq | dt dInt_dv
+    assert np.array_equal(fua.reshape(nv, n).T[:nv], np.zeros((nv, nv)))                                  # fu_top = 0 (:493)
+
+
+def test_rnea_derivative_structure():
+    """branch-induced sparsity: d tau_i / d q_j vanishes when neither joint supports the other; M is symmetric"""
+    from ddp_pinocchio_amd import capi
+    bm = capi.BuiltinModel(capi.BUILTIN_TREE38, 3)
+    o = Oracle(bm, 1)
+    rng = np.random.default_rng(1)
+    N = bm.nv
+    q, v, a = rng.normal(size=N), rng.normal(size=N), rng.normal(size=N)
+    dq, dv, M = o.rnea_derivatives(q, v, a)
+    anc = [set() for _ in range(N)]
+    for i in range(N):
+        j = i
+        while j >= 0:
+            anc[i].add(j)
+            j = int(bm.parent[j])
+    for i in range(N):
+        for j in range(N):
+            if i not in anc[j] and j not in anc[i]:
+                assert dq[i, j] == 0.0 and dv[i, j] == 0.0 and M[i, j] == 0.0
+    assert np.array_equal(M, M.T)
+    assert np.max(np.abs(M - o.crba(q))) <= 1e-13 * np.max(np.abs(M))
