@@ -34,13 +34,14 @@ struct BwdParams {
   int64_t* restarts;
   const BwdJob* jobs;
   int32_t has_tensors;
+  int32_t b0;          // first instance of the group this launch sweeps
 };
 
 constexpr int BS = 256;
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(BS) void bwd_init(BwdParams p) {
-  const int b = blockIdx.x;
+  const int b = p.b0 + blockIdx.x;
   const int s = p.status[b];
   if (s == 2) return;
   const int64_t n = p.d.n;
@@ -418,26 +419,54 @@ int launch_sweep(ddp_hip_ctx* ctx, const BwdParams& p, size_t lds_a, size_t lds_
   return DDP_HIP_OK;
 }
 
-// split path (compile-time shapes): K3 bwd_contract streams the tensors, K4 bwd_riccati does the rest
+// split path (compile-time shapes): K3 bwd_contract streams the tensors, K4 bwd_riccati does the rest.
+// The recursion chains K4(t+1) -> K3(t) -> K4(t) per instance, and K4 is a latency chain on one workgroup per instance
+// (a whole CU's LDS each): run back to back on one stream, K3 leaves HBM idle for as long as K4 takes.  The batch is
+// therefore swept in groups on their own streams, so that K3 of one group streams while K4 of the others factorises.
 template <int NC, int MC>
-int launch_sweep_split(ddp_hip_ctx* ctx, const BwdParams& p) {
+int launch_sweep_split(ddp_hip_ctx* ctx, const BwdParams& p0) {
   const Dims& d = ctx->d;
   const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
   const size_t lds_c = sizeof(double) * (size_t)(NC + (NC + MC) * cn_max + 2 * (NC / 2 + 1) * MC);
   const size_t lds_r = sizeof(double) * (size_t)(2 * NC * (NC + MC));
-  hipLaunchKernelGGL(bwd_init, dim3((unsigned)d.batch), dim3(BS), 0, ctx->stream, p);
-  hipLaunchKernelGGL((bwd_dense0<NC, MC>), dim3((unsigned)d.batch), dim3(BSR), lds_r, ctx->stream, p);
+  const int G = ctx->bwd_groups;
+  const int64_t per = (d.batch + G - 1) / G;
+  if (G > 1) {
+    HIP_TRY(hipEventRecord(ctx->bwd_ev_start, ctx->stream));
+    for (int g = 0; g < G; ++g) HIP_TRY(hipStreamWaitEvent(ctx->bwd_stream[g], ctx->bwd_ev_start, 0));
+  }
+  BwdParams pg[8];
+  unsigned nb[8];
+  hipStream_t st[8];
+  for (int g = 0; g < G; ++g) {
+    pg[g] = p0;
+    pg[g].b0 = (int32_t)(g * per);
+    const int64_t n_ = d.batch - g * per < per ? d.batch - g * per : per;
+    nb[g] = n_ > 0 ? (unsigned)n_ : 0u;
+    st[g] = G > 1 ? ctx->bwd_stream[g] : ctx->stream;
+    if (!nb[g]) continue;
+    hipLaunchKernelGGL(bwd_init, dim3(nb[g]), dim3(BS), 0, st[g], pg[g]);
+    hipLaunchKernelGGL((bwd_dense0<NC, MC>), dim3(nb[g]), dim3(BSR), lds_r, st[g], pg[g]);
+  }
   for (int64_t t = d.T - 1; t >= 0; --t) {
-    if (p.has_tensors) {
-      prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE);
-      hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, (unsigned)d.batch), dim3(BSF), lds_c, ctx->stream, p, t);
-      prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE);
+    for (int g = 0; g < G; ++g) {
+      if (!nb[g]) continue;
+      if (p0.has_tensors) {
+        prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
+        hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, nb[g]), dim3(BSF), lds_c, st[g], pg[g], t);
+        prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
+      }
+      prof_begin(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+      hipLaunchKernelGGL((bwd_riccati<NC, MC>), dim3(nb[g]), dim3(BSR), lds_r, st[g], pg[g], t);
+      prof_end(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
     }
-    prof_begin(ctx, DDP_HIP_K_BWD_GAINS);
-    hipLaunchKernelGGL((bwd_riccati<NC, MC>), dim3((unsigned)d.batch), dim3(BSR), lds_r, ctx->stream, p, t);
-    prof_end(ctx, DDP_HIP_K_BWD_GAINS);
   }
   HIP_TRY(hipGetLastError());
+  if (G > 1)
+    for (int g = 0; g < G; ++g) {
+      HIP_TRY(hipEventRecord(ctx->bwd_ev_done[g], ctx->bwd_stream[g]));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->bwd_ev_done[g], 0));
+    }
   return DDP_HIP_OK;
 }
 
@@ -477,12 +506,33 @@ int bwd_setup(ddp_hip_ctx* ctx) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_riccati<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense0<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
   }
+  if (n == 76 && m == 38) {
+    // groups of the split sweep (tuning knob DDP_HIP_BWD_GROUPS): by default groups of 16 instances, at most 4
+    int64_t G = B / 16;
+    if (G < 1) G = 1;
+    if (G > 4) G = 4;
+    if (const char* ev = getenv("DDP_HIP_BWD_GROUPS")) { const int v = atoi(ev); if (v >= 1 && v <= 8) G = v; }
+    if (G > B) G = B;
+    ctx->bwd_groups = (int32_t)G;
+    if (G > 1) {
+      HIP_TRY(hipEventCreateWithFlags(&ctx->bwd_ev_start, hipEventDisableTiming));
+      for (int g = 0; g < G; ++g) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->bwd_stream[g], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->bwd_ev_done[g], hipEventDisableTiming));
+      }
+    }
+  }
   HIP_TRY(hipMalloc(&ctx->jobs_d, sizeof(BwdJob) * jobs.size()));
   HIP_TRY(hipMemcpy(ctx->jobs_d, jobs.data(), sizeof(BwdJob) * jobs.size(), hipMemcpyHostToDevice));
   return DDP_HIP_OK;
 }
 
 void bwd_teardown(ddp_hip_ctx* ctx) {
+  for (int g = 0; g < 8; ++g) {
+    if (ctx->bwd_stream[g]) { (void)hipStreamSynchronize(ctx->bwd_stream[g]); (void)hipStreamDestroy(ctx->bwd_stream[g]); }
+    if (ctx->bwd_ev_done[g]) (void)hipEventDestroy(ctx->bwd_ev_done[g]);
+  }
+  if (ctx->bwd_ev_start) (void)hipEventDestroy(ctx->bwd_ev_start);
   if (ctx->ws_V) (void)hipFree(ctx->ws_V);
   if (ctx->ws_Q) (void)hipFree(ctx->ws_Q);
   if (ctx->ws_D) (void)hipFree(ctx->ws_D);

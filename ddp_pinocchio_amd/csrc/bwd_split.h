@@ -24,6 +24,7 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
       b = xcd + 8 * (k / njobs);
       jb = k % njobs;
     } else { b = blockIdx.y; jb = blockIdx.x; }
+    b += p.b0;
   }
   if (p.status[b] != 0) return;
   const BwdJob job = p.jobs[jb];
@@ -227,7 +228,7 @@ __device__ __forceinline__ void dense_product(const BwdParams& p, int b, int64_t
 // D for the first step to be processed (t = T-1), from V_xx = lfxx (ddp_bwd.ipp:27)
 template <int N, int M>
 __global__ __launch_bounds__(BSR) void bwd_dense0(BwdParams p) {
-  const int b = blockIdx.x;
+  const int b = p.b0 + blockIdx.x;
   if (p.status[b] != 0) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* s_VW = smem;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(BSR) void bwd_dense0(BwdParams p) {
 
 template <int N, int M>
 __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
-  const int b = blockIdx.x;
+  const int b = p.b0 + blockIdx.x;
   if (p.status[b] != 0) return;
   constexpr int n = N, m = M, nx = N;
   const int64_t T = p.d.T;

@@ -415,8 +415,9 @@ extern "C" int ddp_hip_swap_traj(ddp_hip_ctx* ctx) {
 }
 
 // ---- profiling: HIP events on the context's own stream around every launch of a kernel class --
-void prof_begin(ddp_hip_ctx* ctx, int kid) {
+void prof_begin(ddp_hip_ctx* ctx, int kid, hipStream_t stream) {
   if (!(ctx->profile_mask & (2u << kid))) return;
+  if (!stream) stream = ctx->stream;
   ProfSlot& p = ctx->prof[kid];
   if (p.used == p.starts.size()) {
     hipEvent_t a, b;
@@ -424,17 +425,20 @@ void prof_begin(ddp_hip_ctx* ctx, int kid) {
     p.starts.push_back(a);
     p.stops.push_back(b);
   }
-  (void)hipEventRecord(p.starts[p.used], ctx->stream);
+  (void)hipEventRecord(p.starts[p.used], stream);
 }
-void prof_end(ddp_hip_ctx* ctx, int kid) {
+void prof_end(ddp_hip_ctx* ctx, int kid, hipStream_t stream) {
   if (!(ctx->profile_mask & (2u << kid))) return;
+  if (!stream) stream = ctx->stream;
   ProfSlot& p = ctx->prof[kid];
   if (p.used >= p.stops.size()) return;
-  (void)hipEventRecord(p.stops[p.used], ctx->stream);
+  (void)hipEventRecord(p.stops[p.used], stream);
   ++p.used;
 }
 static void prof_collect(ddp_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
+  for (int g = 0; g < ctx->bwd_groups; ++g)
+    if (ctx->bwd_stream[g]) (void)hipStreamSynchronize(ctx->bwd_stream[g]);
   for (int k = 0; k < DDP_HIP_K_COUNT; ++k) {
     ProfSlot& p = ctx->prof[k];
     for (size_t i = 0; i < p.used; ++i) {

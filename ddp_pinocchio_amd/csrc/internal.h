@@ -90,6 +90,10 @@ struct ddp_hip_ctx {
   BwdJob* jobs_d = nullptr;
   int32_t njobs = 0;
   int32_t cbx = 0, cbu = 0;
+  // the batch is swept in groups on their own streams: K3 of one group overlaps K4 of the others (bwd.hip)
+  int32_t bwd_groups = 1;
+  hipStream_t bwd_stream[8] = {};
+  hipEvent_t bwd_ev_start = nullptr, bwd_ev_done[8] = {};
 
   // forward workspace
   double* fw_x = nullptr;      // [batch][n_alpha_max][(T+1)*nx]
@@ -132,8 +136,8 @@ struct ddp_hip_ctx {
   } while (0)
 
 // profile helpers (ctx.hip)
-void prof_begin(ddp_hip_ctx* ctx, int kid);
-void prof_end(ddp_hip_ctx* ctx, int kid);
+void prof_begin(ddp_hip_ctx* ctx, int kid, hipStream_t stream = nullptr);   // stream: the one the kernel is launched on (default: the context's)
+void prof_end(ddp_hip_ctx* ctx, int kid, hipStream_t stream = nullptr);
 
 // per-op launchers implemented in their own translation units
 int bwd_setup(ddp_hip_ctx* ctx);
