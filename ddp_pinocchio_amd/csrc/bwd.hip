@@ -35,6 +35,7 @@ struct BwdParams {
   const BwdJob* jobs;
   int32_t has_tensors;
   int32_t b0;          // first instance of the group this launch sweeps
+  int32_t c_accumulate; // K3's epilogue adds its contraction to what is already in the Q workspace (bwd_v2.h) instead of storing it
 };
 
 constexpr int BS = 256;
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(BS) void bwd_gains(BwdParams p, int64_t t) {
 
 #include "bwd_fast.h"
 #include "bwd_split.h"
+#include "bwd_v2.h"
 
 size_t assemble_lds_bytes(const ddp_hip_ctx* ctx, int cn_max) {
   const Dims& d = ctx->d;
@@ -470,6 +472,88 @@ int launch_sweep_split(ddp_hip_ctx* ctx, const BwdParams& p0) {
   return DDP_HIP_OK;
 }
 
+// three-kernel step (bwd_v2.h): K5 dense terms on 8 workgroups per instance -> K3 tensor stream (+ P) -> K4' lean Riccati
+template <int NC, int MC>
+int enqueue_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
+  const Dims& d = ctx->d;
+  const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
+  size_t lds_c = sizeof(double) * (size_t)(NC + (NC + MC) * cn_max + 2 * (NC / 2 + 1) * MC);
+  if (ctx->bwd_k3_lds_pad > lds_c) lds_c = ctx->bwd_k3_lds_pad;   // development: limits K3 to one workgroup per CU (room for K4' / K5 of another group)
+  const size_t lds_5 = sizeof(double) * (size_t)(NC * NC + NC * (NC + MC) + NC * CB5 + NC + d.emax);
+  const unsigned nblk5 = (unsigned)((NC + MC + CB5 - 1) / CB5);
+  const int G = ctx->bwd_groups;
+  const int64_t per = (d.batch + G - 1) / G;
+  if (G > 1) {
+    HIP_TRY(hipEventRecord(ctx->bwd_ev_start, ctx->stream));
+    for (int g = 0; g < G; ++g) HIP_TRY(hipStreamWaitEvent(ctx->bwd_stream[g], ctx->bwd_ev_start, 0));
+  }
+  BwdParams pg[8];
+  unsigned nb[8];
+  hipStream_t st[8];
+  for (int g = 0; g < G; ++g) {
+    pg[g] = p0;
+    pg[g].b0 = (int32_t)(g * per);
+    pg[g].c_accumulate = 1;
+    const int64_t n_ = d.batch - g * per < per ? d.batch - g * per : per;
+    nb[g] = n_ > 0 ? (unsigned)n_ : 0u;
+    st[g] = G > 1 ? ctx->bwd_stream[g] : ctx->stream;
+    if (nb[g]) hipLaunchKernelGGL(bwd_init, dim3(nb[g]), dim3(BS), 0, st[g], pg[g]);
+  }
+  for (int64_t t = d.T - 1; t >= 0; --t) {
+    for (int g = 0; g < G; ++g) {
+      if (!nb[g]) continue;
+      prof_begin(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+      hipLaunchKernelGGL((bwd_dense2<NC, MC>), dim3(nblk5, nb[g]), dim3(BS5), lds_5, st[g], pg[g], t);
+      prof_end(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+      if (p0.has_tensors) {
+        prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
+        hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, nb[g]), dim3(BSF), lds_c, st[g], pg[g], t);
+        prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
+      }
+      prof_begin(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+      hipLaunchKernelGGL((bwd_gains2<NC, MC>), dim3(nb[g]), dim3(BS4), 0, st[g], pg[g], t);
+      prof_end(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  if (G > 1)
+    for (int g = 0; g < G; ++g) {
+      HIP_TRY(hipEventRecord(ctx->bwd_ev_done[g], ctx->bwd_stream[g]));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->bwd_ev_done[g], 0));
+    }
+  return DDP_HIP_OK;
+}
+
+// The same enqueue, captured once into a hipGraph per state of the kernel arguments and replayed: the fork / join of
+// the group streams becomes graph edges, the 600 launches per group one submission.  Profiled sweeps (HIP events around
+// kernels) and DDP_HIP_BWD_NO_GRAPH=1 take the direct path.
+template <int NC, int MC>
+int launch_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
+  const uint32_t bwd_mask = (2u << DDP_HIP_K_BWD_ASSEMBLE) | (2u << DDP_HIP_K_BWD_GAINS);
+  if (!ctx->bwd_use_graph || (ctx->profile_mask & bwd_mask)) return enqueue_sweep_v2<NC, MC>(ctx, p0);
+  const void* key_x = p0.x;
+  const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1);
+  ddp_hip_ctx::BwdGraph* slot = nullptr;
+  for (auto& g : ctx->bwd_graph)
+    if (g.exec && g.key_x == key_x && g.key_misc == key_misc) slot = &g;
+  if (!slot) {
+    slot = &ctx->bwd_graph[ctx->bwd_graph_next];
+    ctx->bwd_graph_next = (ctx->bwd_graph_next + 1) % 4;
+    if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
+    if (slot->graph) { (void)hipGraphDestroy(slot->graph); slot->graph = nullptr; }
+    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_sweep_v2<NC, MC>(ctx, p0);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != DDP_HIP_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return rc != DDP_HIP_OK ? rc : DDP_HIP_E_HIP; }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(graph); return DDP_HIP_E_HIP; }
+    slot->graph = graph; slot->exec = exec; slot->key_x = key_x; slot->key_misc = key_misc;
+  }
+  HIP_TRY(hipGraphLaunch(slot->exec, ctx->stream));
+  return DDP_HIP_OK;
+}
+
 }  // namespace
 
 int bwd_setup(ddp_hip_ctx* ctx) {
@@ -505,13 +589,20 @@ int bwd_setup(ddp_hip_ctx* ctx) {
     const size_t lds_r = sizeof(double) * (size_t)(2 * 76 * (76 + 38));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_riccati<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense0<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+    const size_t lds_5 = sizeof(double) * (size_t)(76 * 76 + 76 * (76 + 38) + 76 * CB5 + 76 + d.emax);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense2<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_5));
   }
   if (n == 76 && m == 38) {
-    // groups of the split sweep (tuning knob DDP_HIP_BWD_GROUPS): by default groups of 16 instances, at most 4
-    int64_t G = B / 16;
-    if (G < 1) G = 1;
-    if (G > 4) G = 4;
+    // groups of the sweep on their own streams (tuning knob DDP_HIP_BWD_GROUPS).  Default 1: measured at 64 instances, two
+    // and four groups do not overlap K3 with the other groups' K4' / K5 (K3's workgroups hold every VGPR of the CUs they
+    // run on; 28.7 / 29.7 ms against 30.7 ms)
+    int64_t G = 1;
     if (const char* ev = getenv("DDP_HIP_BWD_GROUPS")) { const int v = atoi(ev); if (v >= 1 && v <= 8) G = v; }
+    ctx->bwd_use_graph = getenv("DDP_HIP_BWD_NO_GRAPH") ? 0 : 1;
+    if (const char* ev = getenv("DDP_HIP_K3_LDS")) {
+      ctx->bwd_k3_lds_pad = (size_t)atoi(ev) * 1024;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_contract<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     if (G > B) G = B;
     ctx->bwd_groups = (int32_t)G;
     if (G > 1) {
@@ -528,6 +619,10 @@ int bwd_setup(ddp_hip_ctx* ctx) {
 }
 
 void bwd_teardown(ddp_hip_ctx* ctx) {
+  for (auto& g : ctx->bwd_graph) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
   for (int g = 0; g < 8; ++g) {
     if (ctx->bwd_stream[g]) { (void)hipStreamSynchronize(ctx->bwd_stream[g]); (void)hipStreamDestroy(ctx->bwd_stream[g]); }
     if (ctx->bwd_ev_done[g]) (void)hipEventDestroy(ctx->bwd_ev_done[g]);
@@ -569,7 +664,7 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
     // the Talos-like shape runs the split K3 / K4 kernels; every other shape (and DDP_HIP_GENERIC_BWD=1, kept for
     // cross-checking the two implementations against each other) the run-time-shaped pair
     const bool generic = getenv("DDP_HIP_GENERIC_BWD") != nullptr;
-    if (d.n == 76 && d.m == 38 && !generic) rc = launch_sweep_split<76, 38>(ctx, p);
+    if (d.n == 76 && d.m == 38 && !generic) rc = getenv("DDP_HIP_BWD_V1") ? launch_sweep_split<76, 38>(ctx, p) : launch_sweep_v2<76, 38>(ctx, p);
     else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6>(ctx, p, lds_a, lds_g);
     else rc = launch_sweep<0, 0>(ctx, p, lds_a, lds_g);
     if (rc != DDP_HIP_OK) return rc;
@@ -589,3 +684,9 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
   if (rc != DDP_HIP_OK) return rc;
   return any_restart ? DDP_HIP_EV_LLT_RESTART : DDP_HIP_OK;
 }
+
+#ifdef BWD_STAMPS
+extern "C" int ddp_hip_debug_stamps(unsigned long long* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_bwd_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -103,12 +103,10 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
   for (int idx = tid; idx < rows * cn; idx += BSF) {
     const int r = idx % rows, c = idx / rows;
     const int col = c0 + c;
-    if (kind == 0) {
-      if (r < n) Cxx[r + col * n] = s_out[idx];
-      else Cux[(r - n) + col * m] = s_out[idx];
-    } else {
-      Cuu[r + col * m] = s_out[idx];
-    }
+    // c_accumulate: the workspace already holds every other term of Q (K5, bwd_v2.h); the tensor term comes last in the
+    // reference as well (ddp_bwd.ipp:75,81,87)
+    double* dst = kind == 0 ? (r < n ? Cxx + r + col * n : Cux + (r - n) + col * m) : Cuu + r + col * m;
+    *dst = p.c_accumulate ? *dst + s_out[idx] : s_out[idx];
   }
 }
 

@@ -1,0 +1,454 @@
+// bwd_v2.h -- the backward step of the Talos shape as three kernels (included by bwd.hip after bwd_split.h):
+//
+//   K5  bwd_dense2<N, M>    grid (column blocks, instances).  P = l + [f_x f_u]^T V_xx [f_x f_u] + multiplier terms: every
+//       term of Q (ddp_bwd.ipp:61-87) except the V_x-contracted dynamics tensors, in the reference's order of terms;
+//       the dense product (3.3 MFLOP per instance and step) on the FP64 matrix cores, spread over 8 workgroups per
+//       instance instead of riding at the tail of the one Riccati workgroup.
+//   K3  bwd_contract<N, M>  (bwd_split.h) streams the tensors; its epilogue finishes Q = P + C (the tensor term comes
+//       last in the reference as well, :75,:81,:87).
+//   K4' bwd_gains2<N, M>    grid (instances), 256 lanes.  LLT of Q_uu + reg I in ONE wave -- lane = row, the row in
+//       registers, the pivot column broadcast through LDS within the wave: no workgroup barrier inside the factorisation
+//       (the round-1 kernel took 76) -- then the 77 right-hand sides [-Q_u | -Q_ux] one per lane against L in LDS, V_x,
+//       and V_xx = Q_xx + Q_ux^T K on the matrix cores.
+//
+// Per instance the chain is K4'(t+1) -> K5(t) -> K3(t) -> K4'(t).  Same arithmetic conventions as bwd_split.h: no
+// symmetrisation, lower triangle only, fail <=> pivot <= 0, per-entry updates in ascending k.
+#pragma once
+
+// development: -DBWD_STAMPS builds in-kernel phase stamps (s_memrealtime, 100 MHz) of instance 0, read by tools/bwd_stamps.py
+#ifdef BWD_STAMPS
+__device__ unsigned long long g_bwd_stamps[32];
+#define STAMP(i) do { if (tid == 0 && b == 0 && blockIdx.x == 0) g_bwd_stamps[i] = wall_clock64(); } while (0)
+#define STAMP_T(i, T_) do { if (tid == (T_) && b == 0 && blockIdx.x == 0) g_bwd_stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_T(i, T_) do { } while (0)
+#endif
+
+constexpr int BS5 = 512;   // workgroup size of K5
+constexpr int BS4 = 256;   // workgroup size of K4'
+constexpr int CB5 = 32;    // columns of F = [f_x | f_u] per K5 workgroup (two MFMA tiles): 4 workgroups per instance
+
+template <int N, int M>
+__global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
+  constexpr int n = N, m = M, NM = N + M;
+  const int b = p.b0 + blockIdx.y;
+  if (p.status[b] != 0) return;
+  const int c0 = blockIdx.x * CB5;                 // first column of this block (0 .. NM-1)
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  constexpr int NW = BS5 / 64;
+  const int64_t T = p.d.T;
+  const int64_t bt = (int64_t)b * T + t;
+  const int e = (int)p.ne[t];
+  const int64_t Eo = p.Epre[t], Etot = p.d.Etot;
+  const double mu = p.mu[b];
+  const bool tens = p.has_tensors != 0;
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_V = smem;                // N * N      V_xx(t+1), column-major
+  double* s_F = s_V + N * N;         // N * NM     F = [f_x | f_u] of step t, column-major ld N
+  double* s_W = s_F + N * NM;        // N * CB5    W = V_xx F(:, block)
+  double* s_vx = s_W + N * CB5;      // N          V_x(t+1)
+  double* s_tmp = s_vx + N;          // emax       pe + mu eq   (ddp_bwd.ipp:46)
+
+  const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
+  const double* Vxx = Vx + n;
+  STAMP(0);
+  {
+    const f64x2* a = reinterpret_cast<const f64x2*>(Vxx);
+    f64x2* d = reinterpret_cast<f64x2*>(s_V);
+    for (int i = tid; i < n * n / 2; i += BS5) d[i] = a[i];
+    const f64x2* fx2 = reinterpret_cast<const f64x2*>(p.fx + bt * n * n);
+    const f64x2* fu2 = reinterpret_cast<const f64x2*>(p.fu + bt * n * m);
+    f64x2* f = reinterpret_cast<f64x2*>(s_F);
+    for (int i = tid; i < n * n / 2; i += BS5) f[i] = fx2[i];
+    for (int i = tid; i < n * m / 2; i += BS5) f[n * n / 2 + i] = fu2[i];
+    for (int i = tid; i < n; i += BS5) s_vx[i] = Vx[i];
+  }
+  const double* eqv = p.eq_val + (int64_t)b * Etot + Eo;
+  const double* eqx = p.eq_x + ((int64_t)b * Etot + Eo) * n;
+  const double* equ = p.eq_u + ((int64_t)b * Etot + Eo) * m;
+  const double* pe = p.mult_val + (int64_t)b * Etot + Eo;
+  const double* pex = p.mult_jac + ((int64_t)b * Etot + Eo) * n;
+  const double* eq_xx = p.eq_xx + ((int64_t)b * Etot + Eo) * n * n;
+  const double* eq_ux = p.eq_ux + ((int64_t)b * Etot + Eo) * m * n;
+  const double* eq_uu = p.eq_uu + ((int64_t)b * Etot + Eo) * m * m;
+  for (int i = tid; i < e; i += BS5) s_tmp[i] = pe[i] + mu * eqv[i];
+  __syncthreads();
+  STAMP(1);
+  double* Q = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m);
+  // Q_x | Q_u of this block's columns (:61-68): l + F^T V_x + multiplier terms -- one lane per column in the last wave (it has
+  // a single tile of the product below), next to the other waves' matrix work
+  if (wave == NW - 1 && lane < CB5 && c0 + lane < NM) {
+    const int c = c0 + lane;
+    const double* col = s_F + c * n;
+    double sacc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < n; ++k) sacc += col[k] * s_vx[k];
+    double acc = c < n ? p.lx[bt * n + c] : p.lu[bt * m + (c - n)];
+    acc += sacc;
+    if (e > 0) {
+      double s1 = 0.0, s2 = 0.0;
+      if (c < n) { for (int k = 0; k < e; ++k) { s1 += eqx[k + c * e] * s_tmp[k]; s2 += pex[k + c * e] * eqv[k]; } acc += s1; acc += s2; }
+      else { for (int k = 0; k < e; ++k) s1 += equ[k + (c - n) * e] * s_tmp[k]; acc += s1; }
+    }
+    Q[c] = acc;
+  }
+
+  constexpr int KS = N / 4;
+  static_assert(N % 4 == 0, "k-steps of 4");
+  // W(:, block) = V_xx F(:, block): row tiles of 16 over the waves.  A(row = i, k) = V(i, k), B(k, col = c) = F(k, c0 + c)
+  constexpr int MT = (N + 15) / 16, CT = CB5 / 16;
+  for (int tile = wave; tile < MT * CT; tile += NW) {
+    const int mt = tile % MT, ct = tile / MT;
+    const int row = 16 * mt + l15, col = c0 + 16 * ct + l15;
+    const bool rok = row < n, cok = col < NM;
+    const double* va = s_V + (rok ? row : 0) + l4 * n;
+    const double* fb = s_F + (cok ? col : 0) * n + l4;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double av = rok ? va[4 * s * n] : 0.0;
+      const double bv = cok ? fb[4 * s] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 16 * mt + l4 + 4 * q;
+      if (r < n) s_W[r + (16 * ct + l15) * n] = acc[q];
+    }
+  }
+  __syncthreads();
+  STAMP(2);
+
+  double* Pxx = Q + n + m;
+  double* Pux = Pxx + n * n;
+  double* Puu = Pux + m * n;
+  // D^T(c, j) = sum_k W(k, c) F(k, j): A(row = c, k) = W(k, c), B(k, col = j) = F(k, j); result (row = c = l4 + 4 q,
+  // col = j = 16 jt + l15): consecutive lanes -> consecutive j, the fast index of every block of Q
+  constexpr int JT = (NM + 15) / 16;
+  for (int tile = wave; tile < JT * CT; tile += NW) {
+    const int jt = tile % JT, ct = tile / JT;
+    const int cb = c0 + 16 * ct;                    // first column of this tile
+    if (cb >= NM) continue;
+    if (cb >= n && 16 * jt + 15 < n) continue;      // (j < n, c >= n): the unused x-u block (wave-uniform)
+    const int j = 16 * jt + l15;
+    const bool jok = j < NM;
+    const double* wa = s_W + (16 * ct + l15) * n + l4;   // W(4 s + l4, c = 16 ct + l15)
+    const double* fb = s_F + (jok ? j : 0) * n + l4;
+    double lv[4];                                    // the cost terms of this lane's four entries, fetched ahead of the product
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = cb + l4 + 4 * q;
+      lv[q] = 0.0;
+      if (c < NM && jok) {
+        if (c < n) lv[q] = j < n ? p.lxx[bt * n * n + j + c * n] : p.lux[bt * m * n + (j - n) + c * m];
+        else if (j >= n) lv[q] = p.luu[bt * m * m + (j - n) + (c - n) * m];
+      }
+    }
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double av = wa[4 * s];
+      const double bv = jok ? fb[4 * s] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = cb + l4 + 4 * q;                // column of Q (x column if < n, else u column)
+      if (c >= NM || !jok) continue;
+      const double dval = acc[q];
+      // entries of Q in the reference's order of terms (ddp_bwd.ipp:70-86): l, f^T V_xx f, multiplier terms, multiplier tensors
+      if (c < n) {
+        if (j < n) {                                // Q_xx(j, c)
+          double a = lv[q];
+          a += dval;
+          if (e > 0) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < e; ++k) {
+              s1 += eqx[k + j * e] * (pex[k + c * e] + mu * eqx[k + c * e]);          // :72
+              s2 += pex[k + j * e] * eqx[k + c * e];                                  // :73
+            }
+            a += s1;
+            a += s2;
+            if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_xx[k + (j + c * n) * e]; a += s3; }   // :74
+          }
+          Pxx[j + c * n] = a;
+        } else {                                    // Q_ux(j - n, c)
+          const int i = j - n;
+          double a = lv[q];
+          a += dval;
+          if (e > 0) {
+            double s1 = 0.0;
+            for (int k = 0; k < e; ++k) s1 += equ[k + i * e] * (pex[k + c * e] + mu * eqx[k + c * e]);   // :85
+            a += s1;
+            if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_ux[k + (i + c * m) * e]; a += s3; }   // :86
+          }
+          Pux[i + c * m] = a;
+        }
+      } else if (j >= n) {                          // Q_uu(j - n, c - n)
+        const int i = j - n, cu = c - n;
+        double a = lv[q];
+        a += dval;
+        if (e > 0) {
+          double s1 = 0.0;
+          for (int k = 0; k < e; ++k) s1 += equ[k + i * e] * equ[k + cu * e];
+          a += s1 * mu;                                                               // :79
+          if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_uu[k + (i + cu * m) * e]; a += s3; }   // :80
+        }
+        Puu[i + cu * m] = a;
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(4);
+}
+
+// readlane of a double (two 32-bit halves through SGPRs)
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffull), l);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), l);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// K4'.  Compact on purpose: a fully unrolled elimination is ~50 KB of straight-line code executed once, and with one wave
+// per SIMD every 64-byte line of it costs an instruction-cache miss (the unrolled first version of this kernel ran 168 us,
+// the round-1 kernel 99 us: both fetch-bound).  Here every elimination is a rolled loop over the pivot whose body has
+// static register indices because the running row / right-hand side is SHIFTED by one entry per step (the pivot is always
+// entry 0): r[p] <- r[p+1] - L(k+1+p, k) r_k.  Entries beyond the triangle meet zero padding of L in LDS.
+template <int N, int M>
+__global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
+  constexpr int n = N, m = M, nx = N, NR = N + 1;
+  constexpr int LD = M | 1;          // odd leading dimensions: conflict-free column walks
+  constexpr int LP = M;              // a shifted column / reversed row holds at most M-1 entries; the rest stays zero (even: 16-byte aligned columns)
+  const int b = p.b0 + blockIdx.x;
+  if (p.status[b] != 0) return;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  constexpr int NW = BS4 / 64;
+  const int64_t T = p.d.T;
+  const int64_t bt = (int64_t)b * T + t;
+
+  __shared__ __attribute__((aligned(16))) double sL[(M + 2) * LP];       // Cholesky factor (lower), column k SHIFTED to its sub-diagonal: sL[k LP + q] = L(k+1+q, k), zero beyond row M-1 (16-byte aligned walks)
+  __shared__ __attribute__((aligned(16))) double sLt_[(M + 2) * LP];      // its rows reversed: sLt[k LP + q] = L(k, k-1-q) (q < k), zero beyond: the back substitution's walk
+  __shared__ __attribute__((aligned(16))) double sU[N * LD];       // Q_ux, column-major (38 x 76)
+  __shared__ __attribute__((aligned(16))) double sK[NR * LD];      // [k | K], column-major (38 x 77)
+  __shared__ double sDinv[M], sQ[N + M];
+  double* const sLt = sLt_ + 2 * LP;   // rows -2, -1 exist (zero): the backward loop prefetches two rows ahead without a clamp
+  __shared__ int s_failed;
+
+  double* Vx = p.ws_V + (int64_t)b * (n + n * n);
+  double* Vxx = Vx + n;
+  const double* Q = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m);
+  const double* Qxx = Q + n + m;
+  const double* Qux = Qxx + n * n;
+  const double* Quu = Qux + m * n;
+
+  STAMP(8);
+  for (int i = tid; i < n + m; i += BS4) sQ[i] = Q[i];
+  for (int idx = tid; idx < m * n; idx += BS4) sU[idx % m + (idx / m) * LD] = Qux[idx];
+  for (int i = tid; i < (M + 2) * LP; i += BS4) { sL[i] = 0.0; sLt_[i] = 0.0; }
+  if (tid == 0) s_failed = 0;
+  // wave 0: row `lane` of the lower triangle of Q_uu + reg I (ddp_bwd.ipp:104), entry j at a[j]
+  double a[M];
+  if (wave == 0) {
+    const double reg = p.reg[b];
+#pragma unroll
+    for (int j = 0; j < M; ++j) a[j] = (lane < m && j <= lane) ? Quu[lane + j * m] + (lane == j ? reg : 0.0) : 0.0;
+  }
+  __syncthreads();
+  STAMP(9);
+  if (wave == 0) {
+    // Cholesky, lower triangle only; fail <=> pivot <= 0 (:105).  Per entry the updates arrive in ascending k: the order
+    // of Eigen's unblocked LLT.  After step k the row is shifted: a[p] holds entry (lane, k+1+p).
+    // Software-pipelined over the columns: the next pivot only needs entry (lane, k+1) updated with column k -- one
+    // broadcast (v_readlane) and one FMA -- so its sqrt and division (the long dependent chain) are issued while the other
+    // 36 entries of the row are still being updated with column k from LDS.
+    bool failed = false;
+    double lik;                                                    // L(lane, k), the finished column k (dk on the diagonal)
+    {
+      const double piv = readlane_f64(a[0], 0);
+      failed = !(piv > 0.0);
+      const double dk = sqrt(piv);
+      lik = lane == 0 ? dk : a[0] / dk;
+      if (lane > 0 && lane < m) { sL[lane - 1] = lik; sLt[lane * LP + (lane - 1)] = lik; }
+      if (lane == 0) sDinv[0] = 1.0 / dk;
+      __builtin_amdgcn_wave_barrier();
+    }
+    const double* cj = static_cast<const double*>(__builtin_assume_aligned(sL, 16));
+#pragma unroll 1
+    for (int k = 0; k < M - 1 && !failed; ++k, cj += LP) {
+      // after this iteration: a[q] = entry (lane, k+1+q) updated with columns 0 .. k (a[0] is consumed into column k+1)
+      // cj[q] = L(k+1+q, k); zero beyond row M-1
+      double Lq[M - 1];
+#pragma unroll
+      for (int q = 1; q < M - 1; ++q) Lq[q] = cj[q];
+      // the critical chain: column k+1
+      const double ljk1 = readlane_f64(lik, k + 1);
+      const double a0n = a[1] - lik * ljk1;
+      const double pivn = readlane_f64(a0n, k + 1);
+      failed = !(pivn > 0.0);
+      const double dkn = sqrt(pivn);
+      const double likn = lane == k + 1 ? dkn : a0n / dkn;
+      // the rest of the row, off the critical path
+#pragma unroll
+      for (int q = 1; q < M - 1; ++q) a[q] = a[q + 1] - lik * Lq[q];
+      if (lane > k + 1 && lane < m) { sL[(k + 1) * LP + (lane - 2 - k)] = likn; sLt[lane * LP + (lane - 2 - k)] = likn; }
+      if (lane == k + 1) sDinv[k + 1] = 1.0 / dkn;
+      __builtin_amdgcn_wave_barrier();
+      lik = likn;
+    }
+    if (failed && lane == 0) s_failed = 1;
+  } else if (wave == 3) {
+    double* fbo = p.fb_origin + bt * nx;
+    const double* xt = p.x + ((int64_t)b * (T + 1) + t) * nx;
+    for (int i = lane; i < nx; i += 64) fbo[i] = xt[i];                        // :134 (harmless if the step fails: the sweep restarts)
+  }
+  __syncthreads();
+  STAMP(10);
+  if (s_failed) {
+    if (tid == 0) {
+      double rg = p.reg[b], mu2 = p.mu[b];
+      if (rg < mu2) rg = mu2;      // :106-108
+      mu2 *= 2;                    // :109
+      rg *= 2;                     // :110
+      p.reg[b] = rg;
+      p.mu[b] = mu2;
+      p.status[b] = 1;
+      p.restarts[b] += 1;
+    }
+    return;
+  }
+  // right-hand sides [-Q_u | -Q_ux] (:135-136): lane rc of waves 1-2 owns column rc in registers; L from LDS (broadcasts)
+  const int rc = tid - 64;
+  if (rc >= 0 && rc < NR) {
+    double r[M];
+#pragma unroll
+    for (int l = 0; l < m; ++l) r[l] = -(rc == 0 ? sQ[n + l] : sU[l + (rc - 1) * LD]);
+    double* out = sK + rc * LD;
+    // forward: y_k = r_k / L_kk, r_l -= L_lk y_k (l > k); the running column is shifted so that the pivot is r[0].
+    // Column k+1 of L is fetched (LDS broadcasts) while column k is applied: two register buffers, the loop unrolled by 2.
+    static_assert(M % 2 == 0, "substitutions unrolled by two");
+    STAMP_T(16, 64);
+    double La[M - 1], Lb[M - 1];
+    {
+      const double* colp = static_cast<const double*>(__builtin_assume_aligned(sL, 16));   // column k (one pointer, constant offsets)
+      double* outp = out;
+#pragma unroll
+      for (int q = 0; q < M - 1; ++q) La[q] = colp[q];
+#pragma unroll 1
+      for (int k = 0; k < m; k += 2) {
+        {
+          const double yk = r[0] * sDinv[k];
+          outp[0] = yk;
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) Lb[q] = colp[LP + q];
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - La[q] * yk;
+        }
+        {
+          const double yk = r[0] * sDinv[k + 1];
+          outp[1] = yk;
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) La[q] = colp[2 * LP + q];      // columns M, M+1 are zero padding
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - Lb[q] * yk;
+        }
+        colp += 2 * LP;
+        outp += 2;
+      }
+    }
+    STAMP_T(17, 64);
+    // backward: x_k = y_k / L_kk, y_i -= L_ki x_k (i < k), k descending; the column is reloaded reversed (r[q] = y_{M-1-q})
+#pragma unroll
+    for (int q = 0; q < m; ++q) r[q] = out[m - 1 - q];
+    {
+      const double* rowp = static_cast<const double*>(__builtin_assume_aligned(sLt + (m - 1) * LP, 16));   // row k reversed: L(k, k-1-q)
+      double* outp = out + (m - 1);
+#pragma unroll
+      for (int q = 0; q < M - 1; ++q) La[q] = rowp[q];
+#pragma unroll 1
+      for (int k = m - 1; k >= 0; k -= 2) {
+        {
+          const double xk = r[0] * sDinv[k];
+          outp[0] = xk;
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) Lb[q] = rowp[q - LP];
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - La[q] * xk;
+        }
+        {
+          const double xk = r[0] * sDinv[k - 1];
+          outp[-1] = xk;
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) La[q] = rowp[q - 2 * LP];      // rows -1, -2 are zero padding
+#pragma unroll
+          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - Lb[q] * xk;
+        }
+        rowp -= 2 * LP;
+        outp -= 2;
+      }
+    }
+    STAMP_T(18, 64);
+    double* dst = rc == 0 ? p.fb_val + bt * m : p.fb_jac + bt * m * n + (rc - 1) * m;
+    for (int l = 0; l < m; ++l) dst[l] = out[l];
+    STAMP_T(19, 64);
+  }
+  __syncthreads();
+  STAMP(11);
+  // V_x = Q_x + Q_ux^T k (:142-143)
+  for (int i = tid; i < n; i += BS4) {
+    double s = 0.0;
+#pragma unroll 2
+    for (int l = 0; l < m; ++l) s += sU[l + i * LD] * sK[l];
+    const double v = sQ[i] + s;
+    Vx[i] = v;
+    if (p.vx_trace) p.vx_trace[bt * n + i] = v;
+  }
+  // V_xx = Q_xx + Q_ux^T K (:145-146) on the matrix cores, transposed so that consecutive lanes own consecutive rows:
+  // D'(j, i) = sum_l K(l, j) Q_ux(l, i): A(row = j, k = l) = K(l, j), B(k = l, col = i) = Q_ux(l, i)
+  constexpr int TT = (N + 15) / 16, KS = (M + 3) / 4, TPW = (TT * TT + NW - 1) / NW;
+  // the Q_xx entries of this wave's tiles are fetched up front, so that their latency hides behind the products
+  double qv[TPW][4];
+#pragma unroll
+  for (int it_ = 0; it_ < TPW; ++it_) {
+    const int tile = wave + it_ * NW;
+    const int jt = tile / TT, it = tile % TT;
+    const int ib = 16 * it + l15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = 16 * jt + l4 + 4 * q;
+      qv[it_][q] = (tile < TT * TT && j < n && ib < n) ? Qxx[ib + j * n] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int it_ = 0; it_ < TPW; ++it_) {
+    const int tile = wave + it_ * NW;
+    if (tile >= TT * TT) break;
+    const int jt = tile / TT, it = tile % TT;
+    const int ja = 16 * jt + l15, ib = 16 * it + l15;
+    const bool jok = ja < n, iok = ib < n;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int l = 4 * s + l4;
+      const double av = (jok && l < m) ? sK[l + (ja + 1) * LD] : 0.0;
+      const double bv = (iok && l < m) ? sU[l + ib * LD] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = 16 * jt + l4 + 4 * q;
+      if (j >= n || !iok) continue;
+      const int o = ib + j * n;
+      const double v = qv[it_][q] + acc[q];
+      Vxx[o] = v;
+      if (p.vxx_trace) p.vxx_trace[bt * n * n + o] = v;
+    }
+  }
+  __syncthreads();
+  STAMP(12);
+  if (t == 0 && tid == 0) p.status[b] = 2;                                     // :149-151
+}

@@ -94,6 +94,13 @@ struct ddp_hip_ctx {
   int32_t bwd_groups = 1;
   hipStream_t bwd_stream[8] = {};
   hipEvent_t bwd_ev_start = nullptr, bwd_ev_done[8] = {};
+  // the sweep as an instantiated hipGraph (600 launches per group and sweep otherwise pay the enqueue cost every time);
+  // one per state of the kernel arguments (the X buffers trade places at every swap_traj)
+  struct BwdGraph { const void* key_x = nullptr; uint64_t key_misc = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
+  BwdGraph bwd_graph[4];
+  int bwd_graph_next = 0;
+  int bwd_use_graph = 1;
+  size_t bwd_k3_lds_pad = 0;
 
   // forward workspace
   double* fw_x = nullptr;      // [batch][n_alpha_max][(T+1)*nx]

@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--T", type=int, default=200)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--no-tensors", action="store_true")
+ap.add_argument("--no-events", action="store_true", help="no HIP events around the kernels: the sweep takes its hipGraph path")
 a = ap.parse_args()
 
 import ctypes as C
@@ -72,8 +73,11 @@ torch.cuda.synchronize()
 
 rc, reg, mu, rs = ctx.backward(0.0, 10.0)
 print("warmup rc", rc, "restarts", rs.sum())
-ctx.profile_enable(True)
+ctx.profile_enable(not a.no_events)
 ctx.profile_reset()
+if a.no_events:
+    ctx.backward(0.0, 10.0)          # captures the graph
+    ctx.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.reps):
     ctx.backward(0.0, 10.0)
