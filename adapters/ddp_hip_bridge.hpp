@@ -28,11 +28,14 @@ inline void check(int rc, char const* where) {
   if (rc < 0) throw std::runtime_error(std::string(where) + ": " + ddp_hip_strerror(rc));
 }
 
-// The model table of the problem's dynamics.  adapters/pinocchio_double.cpp defines model_t<double> with this member;
-// pendulum_model_t (pendulum_model.hpp:10-133) is recognised by its two scalars.
+// The model table of the problem's dynamics.  model_t<double> (adapters/pinocchio_double.cpp) registers its tables by
+// address -- the reference's header declares no accessor and the drop-in does not touch it; pendulum_model_t
+// (pendulum_model.hpp:10-133) is recognised by its two scalars.
+void model_table_of(void const* model, ddp_hip_model& out, ddp_hip_model_storage& st);   // adapters/pinocchio_double.cpp
+void frame_of(void const* model, index_t frame_id, int32_t& joint, double off[3]);
 template <typename Model>
-auto fill_model(Model const& model, ddp_hip_model& out, ddp_hip_model_storage& st) -> decltype(model.hip_model(out, st), void()) {
-  model.hip_model(out, st);
+void fill_model(Model const& model, ddp_hip_model& out, ddp_hip_model_storage& st) {
+  model_table_of(static_cast<void const*>(&model), out, st);
 }
 template <typename Scalar>
 void fill_model(pendulum_model_t<Scalar> const& model, ddp_hip_model& out, ddp_hip_model_storage& st) {
@@ -66,6 +69,15 @@ struct constraint_traits<spatial_constraint_t<Model, View>> { // problem.hpp:631
   static constexpr int advance = 0;
   static auto base(spatial_constraint_t<Model, View> const& c) -> spatial_constraint_t<Model, View> const& { return c; }
 };
+
+template <typename Model, typename View>
+void set_frame(ddp_hip_problem& hp, spatial_constraint_t<Model, View> const& c) {
+  // the library attaches the frame to a joint + an offset in that joint's frame; hip_bridge::frame_of (adapters/
+  // pinocchio_double.cpp) resolves the reference's frame index (problem.hpp:741 m_frame_id)
+  frame_of(static_cast<void const*>(&c.m_dynamics.m_model), c.m_frame_id, hp.frame_joint, hp.frame_off);
+}
+template <typename C>
+void set_frame(ddp_hip_problem&, C const&) {}
 
 struct entry_t {
   ddp_hip_ctx* ctx = nullptr;
@@ -124,15 +136,6 @@ auto entry_for(Solver const& solver) -> entry_t& {
 }
 template <typename Solver>
 auto context_for(Solver const& solver) -> ddp_hip_ctx* { return entry_for(solver).ctx; }
-
-template <typename Model, typename View>
-void set_frame(ddp_hip_problem& hp, spatial_constraint_t<Model, View> const& c) {
-  // the library attaches the frame to a joint + an offset in that joint's frame; model_t<double>::frame_of (adapters/
-  // pinocchio_double.cpp) resolves the reference's frame index (problem.hpp:741 m_frame_id)
-  c.m_dynamics.m_model.frame_of(c.m_frame_id, hp.frame_joint, hp.frame_off);
-}
-template <typename C>
-void set_frame(ddp_hip_problem&, C const&) {}
 
 inline void release(void const* solver) {
   std::lock_guard<std::mutex> lock(registry_mutex());

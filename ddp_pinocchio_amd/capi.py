@@ -47,6 +47,7 @@ EXPORTS = [
     "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_comm_unique_id",
     "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_builtin_model",
     "ddp_hip_batch", "ddp_hip_set_active", "ddp_hip_solve", "ddp_hip_ctx_info",
+    "ddp_hip_model_create", "ddp_hip_model_destroy", "ddp_hip_model_aba", "ddp_hip_model_aba_derivatives", "ddp_hip_model_frame",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -150,6 +151,11 @@ def lib():
     L.ddp_hip_set_active.argtypes = [C.c_void_p, _ip]
     L.ddp_hip_solve.argtypes = [C.c_void_p, C.POINTER(SolverParams), C.POINTER(SolveLog)]
     L.ddp_hip_ctx_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+    L.ddp_hip_model_create.argtypes = [C.POINTER(Model), C.c_int, C.POINTER(C.c_void_p)]
+    L.ddp_hip_model_destroy.argtypes = [C.c_void_p]
+    L.ddp_hip_model_aba.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+    L.ddp_hip_model_aba_derivatives.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.ddp_hip_model_frame.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp]
     _lib = L
     return L
 
@@ -194,6 +200,44 @@ class BuiltinModel:
         self.mass_j = np.array(st.mass_j[:nv])
         self.com = np.array(st.com[:3 * nv]).reshape(nv, 3)
         self.Ic = np.array(st.Ic[:9 * nv]).reshape(nv, 3, 3)
+
+
+class ModelHandle:
+    """Point evaluations of the Model concept on the device (ddp_hip_model_*, seam B2)"""
+
+    def __init__(self, model, device=0):
+        self.model, self.nv = model, model.nv
+        self._h = C.c_void_p()
+        _check(lib().ddp_hip_model_create(C.byref(model.model), device, C.byref(self._h)), "model_create")
+
+    def close(self):
+        if self._h:
+            lib().ddp_hip_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def aba(self, q, v, tau):
+        q, v, tau, out = _f64(q), _f64(v), _f64(tau), np.zeros(self.nv)
+        _check(lib().ddp_hip_model_aba(self._h, _ptr(q), _ptr(v), _ptr(tau), _ptr(out)), "model_aba")
+        return out
+
+    def aba_derivatives(self, q, v, tau):
+        q, v, tau = _f64(q), _f64(v), _f64(tau)
+        n = self.nv
+        dq, dv, dt = np.zeros(n * n), np.zeros(n * n), np.zeros(n * n)
+        _check(lib().ddp_hip_model_aba_derivatives(self._h, _ptr(q), _ptr(v), _ptr(tau), _ptr(dq), _ptr(dv), _ptr(dt)), "model_aba_derivatives")
+        return dq.reshape(n, n).T.copy(), dv.reshape(n, n).T.copy(), dt.reshape(n, n).T.copy()
+
+    def frame(self, joint, off, q, jac=True):
+        off, q = _f64(off), _f64(q)
+        p3, J = np.zeros(3), np.zeros(3 * self.nv)
+        _check(lib().ddp_hip_model_frame(self._h, joint, _ptr(off), _ptr(q), _ptr(p3), _ptr(J) if jac else None), "model_frame")
+        return p3, J.reshape(self.nv, 3).T.copy()
 
 
 class ProblemSpec:

@@ -26,7 +26,7 @@ __device__ unsigned long long g_bwd_stamps[32];
 #endif
 
 constexpr int BS5 = 512;   // workgroup size of K5
-constexpr int BS4 = 256;   // workgroup size of K4'
+constexpr int BS4 = 512;   // workgroup size of K4' (wave 0: LLT, waves 1-2: right-hand sides, all eight: loads and the V update)
 constexpr int CB5 = 32;    // columns of F = [f_x | f_u] per K5 workgroup (two MFMA tiles): 4 workgroups per instance
 
 template <int N, int M>

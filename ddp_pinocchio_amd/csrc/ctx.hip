@@ -119,6 +119,21 @@ static bool build_slot_tables(DevModel& dm) {
   return n_slots <= 8;   // rbd::MAX_SLOTS
 }
 
+// the model table of the C-ABI as the device-side DevModel (shared with model_api.hip)
+void ddp_hip_fill_dev_model(const ddp_hip_model* mo, DevModel& dm) {
+  memset(&dm, 0, sizeof(dm));
+  dm.kind = mo->kind; dm.nv = mo->nv; dm.mass = mo->mass; dm.length = mo->length;
+  for (int k = 0; k < 3; ++k) dm.gravity[k] = mo->gravity[k];
+  if (mo->kind != DDP_HIP_MODEL_TREE) return;
+  for (int i = 0; i < mo->nv; ++i) {
+    dm.parent[i] = mo->parent[i]; dm.jtype[i] = mo->jtype[i];
+    for (int k = 0; k < 3; ++k) { dm.axis[i][k] = mo->axis[3 * i + k]; dm.pp[i][k] = mo->pp[3 * i + k]; }
+    for (int k = 0; k < 9; ++k) dm.Rp[i][k] = mo->Rp[9 * i + k];
+    pack_body_inertia(mo, i, dm.I6[i]);
+  }
+}
+bool ddp_hip_build_tables(DevModel& dm) { return build_slot_tables(dm); }
+
 static int64_t seq_size_of(const Dims& d, int s) {
   const int64_t T = d.T, n = d.n, m = d.m, nx = d.nx, E = d.Etot;
   switch (s) {
@@ -248,21 +263,12 @@ extern "C" int ddp_hip_create(const ddp_hip_problem* prob, int device, uint32_t 
   }
 
   DevModel& dm = ctx->model_h;
-  memset(&dm, 0, sizeof(dm));
-  dm.kind = mo.kind; dm.nv = mo.nv; dm.mass = mo.mass; dm.length = mo.length;
-  for (int k = 0; k < 3; ++k) { dm.gravity[k] = mo.gravity[k]; dm.frame_off[k] = prob->frame_off[k]; }
+  ddp_hip_fill_dev_model(&mo, dm);
+  for (int k = 0; k < 3; ++k) dm.frame_off[k] = prob->frame_off[k];
   dm.dt = prob->dt; dm.c = prob->c;
   dm.eq_kind = prob->eq_kind; dm.eq_advance = prob->eq_advance; dm.frame_joint = prob->frame_joint;
   dm.first_order_fd = prob->first_order_fd; dm.fd_mode = prob->fd_mode;
-  if (mo.kind == DDP_HIP_MODEL_TREE) {
-    for (int i = 0; i < mo.nv; ++i) {
-      dm.parent[i] = mo.parent[i]; dm.jtype[i] = mo.jtype[i];
-      for (int k = 0; k < 3; ++k) { dm.axis[i][k] = mo.axis[3 * i + k]; dm.pp[i][k] = mo.pp[3 * i + k]; }
-      for (int k = 0; k < 9; ++k) dm.Rp[i][k] = mo.Rp[9 * i + k];
-      pack_body_inertia(&mo, i, dm.I6[i]);
-    }
-    if (!build_slot_tables(dm)) { ddp_hip_destroy(ctx); return DDP_HIP_E_UNSUPPORTED; }
-  }
+  if (mo.kind == DDP_HIP_MODEL_TREE && !build_slot_tables(dm)) { ddp_hip_destroy(ctx); return DDP_HIP_E_UNSUPPORTED; }
   CTX_TRY(hipMalloc(&ctx->model_d, sizeof(DevModel)));
   CTX_TRY(hipMemcpy(ctx->model_d, &dm, sizeof(DevModel), hipMemcpyHostToDevice));
 

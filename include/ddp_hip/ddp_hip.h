@@ -244,6 +244,21 @@ int ddp_hip_comm_destroy(ddp_hip_comm* comm);
 int ddp_hip_shard_best(ddp_hip_comm* comm, double local_cost, int64_t local_global_index,
                        double* best_cost, int64_t* best_global_index);
 
+/* ---- the Model concept point by point (pinocchio_model.hpp:77-186), for a host-side model_t<double> (seam B2, see
+ * adapters/pinocchio_double.cpp).  One configuration per call, evaluated on the device by the same rigid-body code the
+ * batched entry points use: plumbing, not a hot path.  Matrices nv x nv column-major. ------------------------------ */
+typedef struct ddp_hip_model_handle ddp_hip_model_handle;
+int ddp_hip_model_create(const ddp_hip_model* model, int device, ddp_hip_model_handle** out);
+int ddp_hip_model_destroy(ddp_hip_model_handle* h);
+/* model_t::dynamics_aba, pinocchio_model.ipp:337-356 */
+int ddp_hip_model_aba(ddp_hip_model_handle* h, const double* q, const double* v, const double* tau, double* qdd);
+/* model_t::d_dynamics_aba, pinocchio_model.ipp:359-400 */
+int ddp_hip_model_aba_derivatives(ddp_hip_model_handle* h, const double* q, const double* v, const double* tau,
+                                  double* dq, double* dv, double* dtau);
+/* model_t::frame_coordinates / d_frame_coordinates, pinocchio_model.ipp:418-462 (J: 3 x nv, may be NULL; the reference's
+ * WORLD-frame rows) */
+int ddp_hip_model_frame(ddp_hip_model_handle* h, int32_t joint, const double off[3], const double* q, double* p3, double* J);
+
 /* ---- built-in seeded model tables (no URDF exists offline: SURVEY.md D4, 8d) -------------- */
 enum { DDP_HIP_BUILTIN_PENDULUM = 0, DDP_HIP_BUILTIN_CHAIN6 = 1, DDP_HIP_BUILTIN_TREE38 = 2 };
 /* fills caller-provided arrays (sized for DDP_HIP_MAX_JOINTS) and points `out` at them */

@@ -1,0 +1,90 @@
+"""The drop-in adapter files (adapters/: seams B1 / B2 of SURVEY.md 8b) cannot be compiled here -- they include the
+reference's headers, which need Eigen / Boost / fmt -- so they are checked as text: every ddp_hip_* call they make must
+exist in include/ddp_hip/ddp_hip.h with the same number of arguments, every DDP_HIP_* constant they use must be defined
+there, and the include guards must be the reference's (that is what makes the include-path seam work).  The dependency-free
+URDF reader is compiled and run."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ADAPTERS = ["adapters/ddp_hip_bridge.hpp", "adapters/ddp/ddp_bwd.ipp", "adapters/ddp/ddp_fwd.ipp", "adapters/pinocchio_double.cpp"]
+
+
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def _declared():
+    header = _strip_comments(open(os.path.join(ROOT, "include", "ddp_hip", "ddp_hip.h")).read())
+    decl = {}
+    for m in re.finditer(r"\b(ddp_hip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        args = m.group(2).strip()
+        decl[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    consts = set(re.findall(r"\b(DDP_HIP_[A-Z0-9_]+)\b", header))
+    return decl, consts
+
+
+def _calls(text):
+    """(name, argument count) of every ddp_hip_*(...) call, matching parentheses"""
+    out = []
+    for m in re.finditer(r"\b(ddp_hip_[a-z0-9_]+)\s*\(", text):
+        i, depth, nargs, seen = m.end(), 1, 0, False
+        while depth and i < len(text):
+            ch = text[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                nargs += 1
+            elif not ch.isspace():
+                seen = True
+            i += 1
+        out.append((m.group(1), nargs + 1 if seen else 0))
+    return out
+
+
+def test_adapter_files_exist_and_call_the_declared_abi():
+    decl, consts = _declared()
+    assert len(decl) > 30
+    types = {"ddp_hip_ctx", "ddp_hip_model", "ddp_hip_model_storage", "ddp_hip_problem", "ddp_hip_model_handle", "ddp_hip_urdf",
+             "ddp_hip_bridge"}
+    n_calls = 0
+    for rel in ADAPTERS:
+        text = _strip_comments(open(os.path.join(ROOT, rel)).read())
+        for name, nargs in _calls(text):
+            if name in types:
+                continue
+            assert name in decl, f"{rel}: {name} is not declared in ddp_hip.h"
+            assert nargs == decl[name], f"{rel}: {name} called with {nargs} arguments, declared with {decl[name]}"
+            n_calls += 1
+        for c in set(re.findall(r"\b(DDP_HIP_[A-Z0-9_]+)\b", text)):
+            if c.endswith("_HPP"):
+                continue
+            assert c in consts, f"{rel}: {c} is not defined in ddp_hip.h"
+    assert n_calls >= 12
+
+
+def test_replacement_headers_keep_the_references_include_guards():
+    # whichever of <adapters>/ddp/ddp_bwd.ipp and <reference>/include/ddp/ddp_bwd.ipp comes first on the include path wins
+    bwd = open(os.path.join(ROOT, "adapters/ddp/ddp_bwd.ipp")).read()
+    fwd = open(os.path.join(ROOT, "adapters/ddp/ddp_fwd.ipp")).read()
+    assert "#ifndef DDP_IMPL_HPP_UBVAKU5V" in bwd and "#ifndef DDP_FWD_TCC_O5KLTLOB" in fwd      # ddp_bwd.ipp:1, ddp_fwd.ipp:1
+    # the members they define are the ones declared at ddp.hpp:845-862, with the reference's parameter names and order
+    for frag in ("control_feedback_t&&", "trajectory_t const&", "typename multiplier_sequence<M>::type const&", "derivative_storage_t const&",
+                 "-> backward_pass_result_t<M>"):
+        assert frag in bwd, frag
+    for frag in ("trajectory_t&", "backward_pass_result_t<M> const&", "bool", "-> scalar_t"):
+        assert frag in fwd, frag
+    tu = open(os.path.join(ROOT, "adapters/pinocchio_double.cpp")).read()
+    assert "template struct model_t<double>;" in tu
+
+
+def test_urdf_reader_builds_and_reads_a_small_arm(tmp_path):
+    exe = tmp_path / "test_urdf"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "host", "test_urdf.cpp"), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert "test_urdf: ok" in out

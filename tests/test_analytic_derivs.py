@@ -149,3 +149,26 @@ def test_analytic_linearize_talos(gpu, T):
             err, scale = float(np.max(np.abs(a - r))), max(1.0, float(np.max(np.abs(r))))
             tol = 1e-12 * scale if key == "f_val" else (1e-10 * scale if key in ("fx", "fu") else 8 * EPS * cond * jscale / E1)
             assert np.all(np.isfinite(a)) and err <= tol, (key, b, t, err, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [1, 2])
+def test_model_point_evaluations(gpu, which):
+    """ddp_hip_model_* (seam B2: what a host-side model_t<double> calls, adapters/pinocchio_double.cpp) against the oracle:
+    dynamics_aba, d_dynamics_aba, frame_coordinates / d_frame_coordinates at a random configuration"""
+    capi = gpu
+    from oracle.binding import Oracle
+    bm = capi.BuiltinModel(which, 1)
+    o = Oracle(bm, 1)
+    rng = np.random.default_rng(12)
+    N = bm.nv
+    q, v, tau = rng.normal(size=N), rng.normal(size=N), 2.0 * rng.normal(size=N)
+    with capi.ModelHandle(bm) as h:
+        assert rel_err(h.aba(q, v, tau), o.aba(q, v, tau)) < 1e-12
+        got, ref = h.aba_derivatives(q, v, tau), o.aba_derivatives(q, v, tau)
+        for g, r in zip(got, ref):
+            assert rel_err(g, r) < 1e-10
+        joint, off = N - 1, np.array([0.01, -0.02, 0.08])
+        p3, J = h.frame(joint, off, q)
+        assert rel_err(p3, o.frame_position(joint, off, q)) < 1e-13
+        assert float(np.max(np.abs(J - o.frame_jacobian(joint, off, q)))) < 1e-12
