@@ -21,7 +21,8 @@ E_ARG, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_MAX_RESTARTS, E_COMM = -1, -2, -3, -4
 
 MODEL_PENDULUM, MODEL_TREE = 0, 1
 EQ_NONE, EQ_CONFIG, EQ_FRAME = 0, 1, 2
-BUILTIN_PENDULUM, BUILTIN_CHAIN6, BUILTIN_TREE38 = 0, 1, 2
+BUILTIN_PENDULUM, BUILTIN_CHAIN6, BUILTIN_TREE38, BUILTIN_CHAIN6_FF, BUILTIN_TREE38_FF = 0, 1, 2, 3, 4
+JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FREEFLYER = 0, 1, 2
 FLAG_NO_TENSORS, FLAG_TRACE = 1, 2
 LIN_COST, LIN_FIRST, LIN_SECOND, LIN_EQ = 1, 2, 4, 8
 
@@ -187,11 +188,14 @@ class BuiltinModel:
         self.storage = ModelStorage()
         self.model = Model()
         _check(lib().ddp_hip_builtin_model(which, seed, C.byref(self.storage), C.byref(self.model)), "builtin_model")
-        nv = self.model.nv
-        self.kind, self.nv = self.model.kind, nv
+        self.kind, self.nv = self.model.kind, self.model.nv
         self.mass, self.length = self.model.mass, self.model.length
         self.gravity = np.array(list(self.model.gravity))
         st = self.storage
+        # a free-flyer root (jtype[0] == JOINT_FREEFLYER) owns six of the nv velocities: nv - 5 joints, nq = nv + 1
+        self.ff = self.kind == MODEL_TREE and st.jtype[0] == JOINT_FREEFLYER
+        self.nj = nv = self.nv - 5 if self.ff else self.nv
+        self.nq = self.nv + 1 if self.ff else self.nv
         self.parent = np.array(st.parent[:nv], dtype=np.int32)
         self.jtype = np.array(st.jtype[:nv], dtype=np.int32)
         self.axis = np.array(st.axis[:3 * nv]).reshape(nv, 3)
@@ -201,12 +205,19 @@ class BuiltinModel:
         self.com = np.array(st.com[:3 * nv]).reshape(nv, 3)
         self.Ic = np.array(st.Ic[:9 * nv]).reshape(nv, 3, 3)
 
+    def neutral(self):
+        """neutral configuration (pinocchio::neutral): zeros, unit quaternion for a free-flyer root"""
+        q = np.zeros(self.nq)
+        if self.ff:
+            q[6] = 1.0
+        return q
+
 
 class ModelHandle:
     """Point evaluations of the Model concept on the device (ddp_hip_model_*, seam B2)"""
 
     def __init__(self, model, device=0):
-        self.model, self.nv = model, model.nv
+        self.model, self.nv, self.nq = model, model.nv, getattr(model, "nq", model.nv)
         self._h = C.c_void_p()
         _check(lib().ddp_hip_model_create(C.byref(model.model), device, C.byref(self._h)), "model_create")
 
@@ -255,7 +266,7 @@ class ProblemSpec:
             first_order_fd = 0 if model.kind == MODEL_PENDULUM else 1
         self.first_order_fd, self.fd_mode = int(first_order_fd), int(fd_mode)
         self.nv = model.nv
-        self.n, self.m, self.nx = 2 * model.nv, model.nv, 2 * model.nv
+        self.n, self.m, self.nx = 2 * model.nv, model.nv, getattr(model, "nq", model.nv) + model.nv
         self.Etot = int(self.ne.sum())
 
     def c_struct(self):

@@ -243,7 +243,8 @@ template <int N, int M>
 __global__ __launch_bounds__(BSR) void bwd_riccati(BwdParams p, int64_t t) {
   const int b = p.b0 + blockIdx.x;
   if (p.status[b] != 0) return;
-  constexpr int n = N, m = M, nx = N;
+  constexpr int n = N, m = M;
+  const int nx = (int)p.d.nx;        // N + 1 with a free-flyer root
   const int64_t T = p.d.T;
   const int tid = threadIdx.x;
   const int64_t bt = (int64_t)b * T + t;

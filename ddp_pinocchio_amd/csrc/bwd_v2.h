@@ -220,7 +220,8 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // entry 0): r[p] <- r[p+1] - L(k+1+p, k) r_k.  Entries beyond the triangle meet zero padding of L in LDS.
 template <int N, int M>
 __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
-  constexpr int n = N, m = M, nx = N, NR = N + 1;
+  constexpr int n = N, m = M, NR = N + 1;
+  const int nx = (int)p.d.nx;        // N + 1 with a free-flyer root
   constexpr int LD = M | 1;          // odd leading dimensions: conflict-free column walks
   constexpr int LP = M;              // a shifted column / reversed row holds at most M-1 entries; the rest stays zero (even: 16-byte aligned columns)
   const int b = p.b0 + blockIdx.x;

@@ -58,7 +58,7 @@ static void pack_body_inertia(const ddp_hip_model* m, int i, double* out21) {
 // Root->leaf (ascending index): a joint's value is kept from when it is processed until its largest-index child
 // has read it.  For a humanoid tree a handful of slots suffice.
 static bool build_slot_tables(DevModel& dm) {
-  const int N = dm.nv;
+  const int N = dm.nj;
   int largest_child[DDP_MAXJ];
   for (int i = 0; i < N; ++i) { dm.has_child[i] = 0; largest_child[i] = -1; dm.slot_up[i] = -1; dm.slot_down[i] = -1; }
   for (int i = 0; i < N; ++i)
@@ -123,9 +123,12 @@ static bool build_slot_tables(DevModel& dm) {
 void ddp_hip_fill_dev_model(const ddp_hip_model* mo, DevModel& dm) {
   memset(&dm, 0, sizeof(dm));
   dm.kind = mo->kind; dm.nv = mo->nv; dm.mass = mo->mass; dm.length = mo->length;
+  dm.ff = (mo->kind == DDP_HIP_MODEL_TREE && mo->jtype && mo->jtype[0] == DDP_HIP_JOINT_FREEFLYER) ? 1 : 0;
+  dm.nj = dm.ff ? mo->nv - 5 : mo->nv;
+  dm.nq = dm.ff ? mo->nv + 1 : mo->nv;
   for (int k = 0; k < 3; ++k) dm.gravity[k] = mo->gravity[k];
   if (mo->kind != DDP_HIP_MODEL_TREE) return;
-  for (int i = 0; i < mo->nv; ++i) {
+  for (int i = 0; i < dm.nj; ++i) {
     dm.parent[i] = mo->parent[i]; dm.jtype[i] = mo->jtype[i];
     for (int k = 0; k < 3; ++k) { dm.axis[i][k] = mo->axis[3 * i + k]; dm.pp[i][k] = mo->pp[3 * i + k]; }
     for (int k = 0; k < 9; ++k) dm.Rp[i][k] = mo->Rp[9 * i + k];
@@ -212,12 +215,23 @@ extern "C" int ddp_hip_create(const ddp_hip_problem* prob, int device, uint32_t 
   if (mo.kind == DDP_HIP_MODEL_PENDULUM && mo.nv != 1) return DDP_HIP_E_ARG;
   if (prob->fd_mode < 0 || prob->fd_mode > 2) return DDP_HIP_E_ARG;
   if (prob->eq_kind != DDP_HIP_EQ_NONE && (!prob->ne || prob->eq_advance < 0 || prob->eq_advance > 4)) return DDP_HIP_E_ARG;
-  if (prob->eq_kind == DDP_HIP_EQ_FRAME && (mo.kind != DDP_HIP_MODEL_TREE || prob->frame_joint < 0 || prob->frame_joint >= mo.nv))
+  if (prob->eq_kind == DDP_HIP_EQ_FRAME && (mo.kind != DDP_HIP_MODEL_TREE || prob->frame_joint < 0 ||
+                                            prob->frame_joint >= (mo.jtype && mo.jtype[0] == DDP_HIP_JOINT_FREEFLYER ? mo.nv - 5 : mo.nv)))
     return DDP_HIP_E_ARG;
+  bool ff = false;
   if (mo.kind == DDP_HIP_MODEL_TREE) {
     if (!mo.parent || !mo.jtype || !mo.axis || !mo.Rp || !mo.pp || !mo.mass_j || !mo.com || !mo.Ic) return DDP_HIP_E_ARG;
-    for (int i = 0; i < mo.nv; ++i)
+    ff = mo.jtype[0] == DDP_HIP_JOINT_FREEFLYER;
+    const int nj = ff ? mo.nv - 5 : mo.nv;
+    if (nj < 1 || (ff && mo.parent[0] != -1)) return DDP_HIP_E_ARG;
+    for (int i = 0; i < nj; ++i) {
       if (mo.parent[i] >= i || mo.parent[i] < -1) return DDP_HIP_E_ARG;
+      if (i > 0 && mo.jtype[i] != DDP_HIP_JOINT_REVOLUTE && mo.jtype[i] != DDP_HIP_JOINT_PRISMATIC) return DDP_HIP_E_ARG;   // one free flyer, at the root
+    }
+    // Lie-group configurations: forward-differenced jacobians (the north star) and mode 2 / tensor-free only -- the
+    // reference's mode 1 asserts nq == nv itself (problem.hpp:78-81); the config constraint subtracts configurations
+    // (problem.hpp:785-790), meaningless on a quaternion: frame constraints only
+    if (ff && (!prob->first_order_fd || prob->fd_mode == 1 || prob->eq_kind == DDP_HIP_EQ_CONFIG)) return DDP_HIP_E_UNSUPPORTED;
   }
   int ndev = ddp_hip_device_count();
   if (ndev <= 0) return DDP_HIP_E_NODEVICE;
@@ -230,7 +244,7 @@ extern "C" int ddp_hip_create(const ddp_hip_problem* prob, int device, uint32_t 
   ctx->flags = flags;
   ctx->active_h.assign((size_t)prob->batch, 1);
   Dims& d = ctx->d;
-  d.T = prob->T; d.nv = mo.nv; d.n = 2 * (int64_t)mo.nv; d.m = mo.nv; d.nx = 2 * (int64_t)mo.nv; d.batch = prob->batch;
+  d.T = prob->T; d.nv = mo.nv; d.n = 2 * (int64_t)mo.nv; d.m = mo.nv; d.nx = 2 * (int64_t)mo.nv + (ff ? 1 : 0); d.batch = prob->batch;
   ctx->ne_h.assign((size_t)d.T, 0);
   ctx->Epre_h.assign((size_t)d.T + 1, 0);
   d.emax = 0;
@@ -392,7 +406,7 @@ extern "C" int ddp_hip_ctx_info(const ddp_hip_ctx* ctx, ddp_hip_info* out) {
   out->lin_path = ctx->model_h.kind == DDP_HIP_MODEL_PENDULUM ? 0 : (ctx->lin_static ? 1 + ctx->lin_static : 1);
   out->first_order = ctx->model_h.kind == DDP_HIP_MODEL_PENDULUM ? 0 : (ctx->model_h.first_order_fd ? 1 : 2);
   out->bwd_path = (d.n == 76 && d.m == 38 && getenv("DDP_HIP_GENERIC_BWD") == nullptr) ? 1 : 0;
-  out->fwd_path = (ctx->model_h.kind == DDP_HIP_MODEL_TREE && d.Etot == 0 && d.nv == 38 && ctx->model_h.max_level_width <= 8 &&
+  out->fwd_path = (ctx->model_h.kind == DDP_HIP_MODEL_TREE && !ctx->model_h.ff && d.Etot == 0 && d.nv == 38 && ctx->model_h.max_level_width <= 8 &&
                    getenv("DDP_HIP_FWD_SCRATCH") == nullptr) ? 1 : 0;
   out->has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
   int64_t bytes = 0;

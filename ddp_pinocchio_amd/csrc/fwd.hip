@@ -38,8 +38,8 @@ struct FwdParams {
 // eq_advance times around config_constraint_t (:792-806) or spatial_constraint_t (:679-689)
 template <int NJ>
 __device__ void eval_eq(const DevModel& m, const double* target, int e, const double* x, const double* u, double* out) {
-  const int nx = 2 * m.nv;
-  double xa[2 * NJ], xb[2 * NJ];
+  const int nx = m.nq + m.nv;
+  double xa[2 * NJ + 1], xb[2 * NJ + 1];
   for (int i = 0; i < nx; ++i) xa[i] = x[i];
   for (int k = 0; k < m.eq_advance; ++k) {
     rbd::eval_f<NJ>(m, xa, u, xb);
@@ -57,7 +57,7 @@ __device__ void eval_eq(const DevModel& m, const double* target, int e, const do
 // one term of cost_seq_aug (ddp.hpp:730): l + pe.ce + mu/2 |ce|^2
 template <int NJ>
 __device__ double stage_cost(const FwdParams& p, const DevModel& m, int b, int64_t t, const double* x, const double* u, double mu) {
-  const int nv = m.nv, n = 2 * nv, nx = 2 * nv;
+  const int nv = m.nv, n = 2 * nv, nx = m.nq + nv;
   double un = 0;
   for (int i = 0; i < nv; ++i) un += u[i] * u[i];
   double cost = 0.5 * m.c * un;                                   // problem_t::l, problem.hpp:937-942
@@ -70,10 +70,12 @@ __device__ double stage_cost(const FwdParams& p, const DevModel& m, int b, int64
     const double* val = p.mult_val + (int64_t)b * Etot + Eo;
     const double* jac = p.mult_jac + ((int64_t)b * Etot + Eo) * n;
     double dot = 0, sq = 0;
+    double dxo[2 * NJ];
+    if (m.ff) lie::difference_x(m, org, x, dxo);                  // x (-) origin on the group
     for (int i = 0; i < e; ++i) {
       double pe = val[i];                                         // mat_seq_common.hpp:105-115
       double s = 0;
-      for (int l = 0; l < n; ++l) s += jac[i + (int64_t)l * e] * (x[l] - org[l]);
+      for (int l = 0; l < n; ++l) s += jac[i + (int64_t)l * e] * (m.ff ? dxo[l] : x[l] - org[l]);
       pe += s;
       dot += pe * ce[i];
       sq += ce[i] * ce[i];
@@ -89,10 +91,10 @@ __global__ void rollout_kernel(FwdParams p) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.d.batch) return;
   const DevModel& m = *p.model;
-  const int nx = 2 * m.nv, nu = m.nv;
+  const int nx = m.nq + m.nv, nu = m.nv;
   double* xs = const_cast<double*>(p.x_old) + (int64_t)b * (p.d.T + 1) * nx;
   const double* us = p.u_old + (int64_t)b * p.d.T * nu;
-  double x[2 * NJ], xn[2 * NJ], u[NJ];
+  double x[2 * NJ + 1], xn[2 * NJ + 1], u[NJ];
   for (int i = 0; i < nx; ++i) x[i] = xs[i];
   for (int64_t t = 0; t < p.d.T; ++t) {
     for (int i = 0; i < nu; ++i) u[i] = us[t * nu + i];
@@ -110,12 +112,12 @@ __global__ void cost_kernel(FwdParams p, int which) {
   const int b = (int)(gid / (T + 1));
   const int64_t t = gid % (T + 1);
   const DevModel& m = *p.model;
-  const int nx = 2 * m.nv, nu = m.nv;
+  const int nx = m.nq + m.nv, nu = m.nv;
   double* out = (which == 0 ? p.costs_old : p.costs_new) + (int64_t)b * (T + 1);
   if (t == T) { out[T] = 0.0; return; }                           // problem_t::lf, problem.hpp:932-936
   const double* xs = (which == 0 ? p.x_old : p.x_new) + ((int64_t)b * (T + 1) + t) * nx;
   const double* us = (which == 0 ? p.u_old : p.u_new) + ((int64_t)b * T + t) * nu;
-  double x[2 * NJ], u[NJ];
+  double x[2 * NJ + 1], u[NJ];
   for (int i = 0; i < nx; ++i) x[i] = xs[i];
   for (int i = 0; i < nu; ++i) u[i] = us[i];
   out[t] = stage_cost<NJ>(p, m, b, t, x, u, p.mu[b]);
@@ -134,7 +136,7 @@ __global__ void forward_kernel(FwdParams p) {
   if (cand > 33) { p.fw_dcost[(int64_t)b * na + a] = INFINITY; return; }   // 2^-34 < 1e-10: never tried (ddp_fwd.ipp:35-37)
   const double step = ldexp(1.0, -cand);
   const DevModel& m = *p.model;
-  const int nv = m.nv, n = 2 * nv, nx = 2 * nv, nu = nv;
+  const int nv = m.nv, n = 2 * nv, nx = m.nq + nv, nu = nv;
   const int64_t T = p.d.T;
   const double mu = p.mu[b];
   const double* xo = p.x_old + (int64_t)b * (T + 1) * nx;
@@ -142,14 +144,15 @@ __global__ void forward_kernel(FwdParams p) {
   double* xw = p.fw_x + ((int64_t)b * na + a) * (T + 1) * nx;
   double* uw = p.fw_u + ((int64_t)b * na + a) * T * nu;
   const double* cold = p.costs_old + (int64_t)b * (T + 1);
-  double x[2 * NJ], xn[2 * NJ], u[NJ], dx[2 * NJ];
+  double x[2 * NJ + 1], xn[2 * NJ + 1], u[NJ], dx[2 * NJ];
   const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
   for (int i = 0; i < nx; ++i) { x[i] = x0[i]; xw[i] = x0[i]; }
   double dsum = 0.0;
   for (int64_t t = 0; t < T; ++t) {
     const double* k = p.fb_val + ((int64_t)b * T + t) * nu;
     const double* K = p.fb_jac + ((int64_t)b * T + t) * nu * n;
-    for (int i = 0; i < n; ++i) dx[i] = x[i] - xo[t * nx + i];                // :45 difference(out, old, new)
+    if (m.ff) lie::difference_x(m, xo + t * nx, x, dx);                       // :45 difference(out, old, new)
+    else for (int i = 0; i < n; ++i) dx[i] = x[i] - xo[t * nx + i];
     for (int i = 0; i < nu; ++i) u[i] = uo[t * nu + i] + step * k[i];         // :47-48
     for (int i = 0; i < nu; ++i) {
       double s = 0;
@@ -415,7 +418,7 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
     p.round = round;
     prof_begin(ctx, DDP_HIP_K_FWD_ROLLOUT);
     // tree models without constraints: the latency path (one workgroup per instance, 8 lanes per candidate)
-    const bool lat_path = ctx->model_h.kind == DDP_HIP_MODEL_TREE && d.Etot == 0 && n_alpha <= 8 && d.nv == 38 &&
+    const bool lat_path = ctx->model_h.kind == DDP_HIP_MODEL_TREE && !ctx->model_h.ff && d.Etot == 0 && n_alpha <= 8 && d.nv == 38 &&
                           ctx->model_h.max_level_width <= 8 && getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
     if (lat_path) {
       const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));

@@ -13,7 +13,8 @@
 // Device-side model table (tree of 1-DoF joints or the closed-form pendulum); lives in HBM, read
 // through the scalar / L2 path by every dynamics kernel.
 struct DevModel {
-  int32_t kind, nv;
+  int32_t kind, nv;              // nv: velocity (tangent) dimension
+  int32_t ff, nj, nq, pad0_;     // free-flyer root (SE(3), lie.h); number of joints (nv - 5 with a free flyer, else nv); configuration dimension
   double mass, length;
   double gravity[3];
   double dt, c;

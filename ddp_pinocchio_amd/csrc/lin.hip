@@ -61,8 +61,8 @@ __global__ void lin_base_kernel(LinParams p) {
   const int b = (int)(gid / T);
   const int64_t t = gid % T;
   const DevModel& m = *p.model;
-  const int nx = 2 * m.nv;
-  double x[2 * NJ], u[NJ], f[2 * NJ];
+  const int nx = (int)p.d.nx;
+  double x[2 * NJ + 1], u[NJ], f[2 * NJ + 1];
   load_xu<NJ>(p, b, t, x, u);
   rbd::eval_f<NJ>(m, x, u, f);
   for (int i = 0; i < nx; ++i) p.f_val[gid * nx + i] = f[i];
@@ -92,14 +92,20 @@ __global__ void lin_first_kernel(LinParams p) {
   const int b = (int)(bt / T);
   const int64_t t = bt % T;
   const DevModel& m = *p.model;
-  double x[2 * NJ], u[NJ], f[2 * NJ];
+  double x[2 * NJ + 1], u[NJ], f[2 * NJ + 1];
   load_xu<NJ>(p, b, t, x, u);
   const double eps = sqrt(DBL_EPSILON);
-  if (j < n) x[j] = x[j] + eps; else u[j - n] = u[j - n] + eps;
+  if (j < n) lie::perturb_x(m, x, j, eps); else u[j - n] = u[j - n] + eps;      // integrate_x / integrate_u (problem.hpp:107,117-118)
   rbd::eval_f<NJ>(m, x, u, f);
-  const double* f0 = p.f_val + bt * n;
+  const double* f0 = p.f_val + bt * p.d.nx;
   double* col = j < n ? p.fx + bt * n * n + (int64_t)j * n : p.fu + bt * n * mm + (int64_t)(j - n) * n;
-  for (int k = 0; k < n; ++k) col[k] = (f[k] - f0[k]) / eps;
+  if (m.ff) {
+    double df[2 * NJ];
+    lie::difference_x(m, f0, f, df);                                             // difference_out on the group
+    for (int k = 0; k < n; ++k) col[k] = df[k] / eps;
+  } else {
+    for (int k = 0; k < n; ++k) col[k] = (f[k] - f0[k]) / eps;
+  }
 }
 
 // ---- second order, mode 2 (problem.hpp:152-298) --------------------------------------------------------
@@ -158,13 +164,13 @@ __global__ void lin_diag_kernel(LinParams p) {
   const int b = (int)(bt / T);
   const int64_t t = bt % T;
   const DevModel& m = *p.model;
-  double x[2 * NJ], u[NJ], f1[2 * NJ];
+  double x[2 * NJ + 1], u[NJ], f1[2 * NJ + 1];
   load_xu<NJ>(p, b, t, x, u);
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
   const bool at_x = i < n;
   const int idx = at_x ? i : i - n;
-  if (at_x) x[idx] = x[idx] + eps; else u[idx] = u[idx] + eps;
+  if (at_x) lie::perturb_x(m, x, idx, eps); else u[idx] = u[idx] + eps;
   if (p.qcache) {
     const int nv = m.nv, cfg = (at_x && idx < nv) ? 1 + idx : 0;
     const double* qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
@@ -173,12 +179,17 @@ __global__ void lin_diag_kernel(LinParams p) {
   } else {
     rbd::eval_f<NJ>(m, x, u, f1);
   }
-  const double* f0 = p.f_val + bt * n;
+  const double* f0 = p.f_val + bt * p.d.nx;
   const double* fcol = at_x ? p.fx + bt * n * n + (int64_t)idx * n : p.fu + bt * n * mm + (int64_t)idx * n;
   double* tensor = at_x ? p.fxx + bt * n * n * n : p.fuu + bt * n * mm * mm;
   const int L = at_x ? n : mm;
+  if (m.ff) {                       // difference_out on the group (problem.hpp:206), then the vector-space expression
+    double dfv[2 * NJ];
+    lie::difference_x(m, f0, f1, dfv);
+    for (int k = 0; k < n; ++k) f1[k] = dfv[k];
+  }
   for (int k = 0; k < n; ++k) {
-    double df = f1[k] - f0[k];      // difference_out
+    double df = m.ff ? f1[k] : f1[k] - f0[k];      // difference_out
     df -= eps * fcol[k];
     df *= 2;
     tensor[k + (int64_t)idx * n + (int64_t)idx * n * L] = df / eps2;
@@ -230,8 +241,8 @@ __global__ __launch_bounds__(LBS, (PAIRS == 1 || PAIRS == 0 ? 4 : 5)) void lin_o
   const double eps2 = eps * eps;
   // PAIRS == 3 keeps no private copy of x, u or f(x+dx): the control is read through a functor and the output
   // rows are formed on the fly from the accelerations
-  double f1[PAIRS == 3 ? 1 : 2 * NJ], qdd[PAIRS == 3 ? NJ : 1];
-  const double* xg = p.x + ((int64_t)b * (T + 1) + t) * n;
+  double f1[PAIRS == 3 ? 1 : 2 * NJ + 1], qdd[PAIRS == 3 ? NJ : 1];
+  const double* xg = p.x + ((int64_t)b * (T + 1) + t) * p.d.nx;
   const double* ug = p.u + ((int64_t)b * T + t) * mm;
   if (valid) {
     if (PAIRS == 3) {
@@ -242,15 +253,29 @@ __global__ __launch_bounds__(LBS, (PAIRS == 1 || PAIRS == 0 ? 4 : 5)) void lin_o
                             p.vcache + (bt * (2 * nv + 1) + vcfg) * (int64_t)nv * rbd::VC_STRIDE,
                             [&](int k) { double v = ug[k]; if (k == iu) v = v + eps; if (k == ju) v = v + eps; return v; }, qdd);
     } else {
-      double x[2 * NJ], u[NJ];
+      double x[2 * NJ + 1], u[NJ];
       load_xu<NJ>(p, b, t, x, u);
-      if (i < n) x[i] = x[i] + eps; else u[i - n] = u[i - n] + eps;
-      if (j < n) x[j] = x[j] + eps; else u[j - n] = u[j - n] + eps;
+      // both directions in ONE step of the group (integrate_x of dx = eps e_i + eps e_j, problem.hpp:262-263): on a vector
+      // space the two additions commute; on SE(3) the base twist eps (e_i + e_j) is integrated once
+      if (PAIRS == 0 && m.ff && i < 6 && j < 6) {
+        double nu[6] = {0, 0, 0, 0, 0, 0}, q7[7];
+        nu[i] = eps; nu[j] = eps;
+        lie::se3_integrate(x, nu, q7);
+        for (int k = 0; k < 7; ++k) x[k] = q7[k];
+      } else {
+        if (i < n) lie::perturb_x(m, x, i, eps); else u[i - n] = u[i - n] + eps;
+        if (j < n) lie::perturb_x(m, x, j, eps); else u[j - n] = u[j - n] + eps;
+      }
       if (PAIRS == 2) {
         const int cfg = i < nv ? 1 + i : 0;
         rbd::eval_f_cached<NJ>(m, p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE, x, u, f1);
       } else {
         rbd::eval_f<NJ>(m, x, u, f1);
+        if (PAIRS == 0 && m.ff) {     // difference_out on the group (problem.hpp:268); the output stage then subtracts nothing
+          double dfv[2 * NJ];
+          lie::difference_x(m, p.f_val + bt * p.d.nx, f1, dfv);
+          for (int k = 0; k < n; ++k) f1[k] = dfv[k];
+        }
       }
     }
   }
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(LBS, (PAIRS == 1 || PAIRS == 0 ? 4 : 5)) void lin_o
       const int64_t bte = s_bt[e];
       const bool at_x_1 = ie < n, at_x_2 = je < n;
       const int idx_1 = at_x_1 ? ie : ie - n, idx_2 = at_x_2 ? je : je - n;
-      const double* f0 = p.f_val + bte * n;
+      const double* f0 = p.f_val + bte * p.d.nx;
       double* fxx = p.fxx + bte * n * n * n;
       double* fux = p.fux + bte * n * mm * n;
       double* fuu = p.fuu + bte * n * mm * mm;
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(LBS, (PAIRS == 1 || PAIRS == 0 ? 4 : 5)) void lin_o
       int L;
       if (at_x_1) { if (at_x_2) { tensor = fxx; L = n; } else { tensor = fux; L = mm; } }
       else { tensor = fuu; L = mm; }
-      double df = s_f[kk][e] - f0[k];                     // difference_out
+      double df = (PAIRS == 0 && m.ff) ? s_f[kk][e] : s_f[kk][e] - f0[k];   // difference_out
       df -= eps * fcol_1[k];
       df -= eps * fcol_2[k];
       df *= 2;
@@ -366,8 +391,8 @@ __global__ void lin_first_analytic_small_kernel(LinParams p) {
 // constraint value through the advance chain (problem.hpp:563-567)
 template <int NJ>
 __device__ void eq_eval(const DevModel& m, const double* target, int e, const double* x, const double* u, double* out) {
-  const int nx = 2 * m.nv;
-  double xa[2 * NJ], xb[2 * NJ];
+  const int nx = m.nq + m.nv;
+  double xa[2 * NJ + 1], xb[2 * NJ + 1];
   for (int i = 0; i < nx; ++i) xa[i] = x[i];
   for (int k = 0; k < m.eq_advance; ++k) {
     rbd::eval_f<NJ>(m, xa, u, xb);
@@ -440,13 +465,13 @@ __global__ void eq_chain_kernel(LinParams p) {
   const int e = (int)p.ne[t];
   if (e == 0) return;
   const DevModel& m = *p.model;
-  const int nv = m.nv, n = 2 * nv, K = m.eq_advance;
+  const int nv = m.nv, n = 2 * nv, K = m.eq_advance, nx = (int)p.d.nx;
   const int64_t Eo = p.Epre[t], Eb = (int64_t)b * p.d.Etot + Eo;
-  double xa[2 * NJ], xb[2 * NJ], u[NJ];
+  double xa[2 * NJ + 1], xb[2 * NJ + 1], u[NJ];
   load_xu<NJ>(p, b, t, xa, u);
   for (int k = 0; k < K; ++k) {                          // x_{k+1} = f(x_k, u): the SAME u at every look-ahead step
     rbd::eval_f<NJ>(m, xa, u, xb);
-    for (int i = 0; i < n; ++i) { xa[i] = xb[i]; p.eq_xk[(gid * K + k) * n + i] = xb[i]; }
+    for (int i = 0; i < nx; ++i) { xa[i] = xb[i]; p.eq_xk[(gid * K + k) * nx + i] = xb[i]; }
   }
   double* C = p.eq_c + gid * (int64_t)p.d.emax * n;
   for (int i = 0; i < e * n; ++i) C[i] = 0.0;
@@ -476,17 +501,24 @@ __global__ void eq_fdjac_kernel(LinParams p) {
   const int b = (int)(bt / T);
   const int64_t t = bt % T;
   if (p.ne[t] == 0) return;
-  double x[2 * NJ], u[NJ], f[2 * NJ];
-  const double* xk = p.eq_xk + (bt * K + k) * n;           // x_{k+1}
-  const double* xk1 = p.eq_xk + (bt * K + k + 1) * n;      // x_{k+2} = f(x_{k+1}, u)
+  double x[2 * NJ + 1], u[NJ], f[2 * NJ + 1];
+  const int nx = (int)p.d.nx;
+  const double* xk = p.eq_xk + (bt * K + k) * nx;          // x_{k+1}
+  const double* xk1 = p.eq_xk + (bt * K + k + 1) * nx;     // x_{k+2} = f(x_{k+1}, u)
   const double* us = p.u + ((int64_t)b * T + t) * m.nv;
-  for (int i = 0; i < n; ++i) x[i] = xk[i];
+  for (int i = 0; i < nx; ++i) x[i] = xk[i];
   for (int i = 0; i < m.nv; ++i) u[i] = us[i];
   const double eps = sqrt(DBL_EPSILON);
-  x[j] = x[j] + eps;
+  lie::perturb_x(m, x, j, eps);
   rbd::eval_f<NJ>(m, x, u, f);
   double* col = p.eq_fxk + (bt * (K - 1) + k) * (int64_t)n * n + (int64_t)j * n;
-  for (int i = 0; i < n; ++i) col[i] = (f[i] - xk1[i]) / eps;
+  if (m.ff) {
+    double df[2 * NJ];
+    lie::difference_x(m, xk1, f, df);
+    for (int i = 0; i < n; ++i) col[i] = df[i] / eps;
+  } else {
+    for (int i = 0; i < n; ++i) col[i] = (f[i] - xk1[i]) / eps;
+  }
 }
 
 // eq_x = C f_x(x_{K-1}) ... f_x(x_1) f_x(x_0),  eq_u = C f_x(x_{K-1}) ... f_x(x_1) f_u(x_0)   (problem.hpp:603-604)
@@ -634,7 +666,7 @@ __global__ void eq_second_m2_kernel(LinParams p, int stage) {
   }
   const DevModel& m = *p.model;
   constexpr int EM = NJ > 3 ? NJ : 3;
-  double x[2 * NJ], u[NJ], f1[EM];
+  double x[2 * NJ + 1], u[NJ], f1[EM];
   load_xu<NJ>(p, b, t, x, u);
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
@@ -645,7 +677,13 @@ __global__ void eq_second_m2_kernel(LinParams p, int stage) {
   double* euu = p.eq_uu + Eb * mm * mm;
   const bool at_x_1 = i < n;
   const int idx_1 = at_x_1 ? i : i - n;
-  if (at_x_1) x[idx_1] = x[idx_1] + eps; else u[idx_1] = u[idx_1] + eps;
+  const bool both_base = stage != 0 && m.ff && i < 6 && j < 6;     // one step of the group for a pair of base directions
+  if (both_base) {
+    double nu[6] = {0, 0, 0, 0, 0, 0}, q7[7];
+    nu[i] = eps; nu[j] = eps;
+    lie::se3_integrate(x, nu, q7);
+    for (int k = 0; k < 7; ++k) x[k] = q7[k];
+  } else if (at_x_1) lie::perturb_x(m, x, idx_1, eps); else u[idx_1] = u[idx_1] + eps;
   const double* fcol_1 = at_x_1 ? p.eq_x + Eb * n + (int64_t)idx_1 * e : p.eq_u + Eb * mm + (int64_t)idx_1 * e;
   const int L1 = at_x_1 ? n : mm;
   double* tensor_1 = at_x_1 ? exx : euu;
@@ -661,7 +699,7 @@ __global__ void eq_second_m2_kernel(LinParams p, int stage) {
   }
   const bool at_x_2 = j < n;
   const int idx_2 = at_x_2 ? j : j - n;
-  if (at_x_2) x[idx_2] = x[idx_2] + eps; else u[idx_2] = u[idx_2] + eps;
+  if (both_base) {} else if (at_x_2) lie::perturb_x(m, x, idx_2, eps); else u[idx_2] = u[idx_2] + eps;
   const double* fcol_2 = at_x_2 ? p.eq_x + Eb * n + (int64_t)idx_2 * e : p.eq_u + Eb * mm + (int64_t)idx_2 * e;
   const int L2 = at_x_2 ? n : mm;
   const double* tensor_2 = at_x_2 ? exx : euu;
@@ -827,7 +865,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
   // q-part cache of the mode-2 stencil (tree models with resident tensors only)
   const bool tree = ctx->model_h.kind == DDP_HIP_MODEL_TREE;
   const bool tensors = ctx->model_h.fd_mode == 2 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS);
-  const bool want = tree && tensors && getenv("DDP_HIP_NO_QCACHE") == nullptr;
+  const bool want = tree && tensors && !ctx->model_h.ff && getenv("DDP_HIP_NO_QCACHE") == nullptr;   // the caches index q by joint: 1-DoF trees
   const int topo = (tree && getenv("DDP_HIP_NO_STATIC") == nullptr) ? lin_static_supported(ctx->model_h) : 0;
   const Dims& d = ctx->d;
   if (want) { ctx->lin_ncfg = (int32_t)d.nv + 1; ctx->lin_nvcfg = 2 * (int32_t)d.nv + 1; }
@@ -860,7 +898,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
     if (rc_ != DDP_HIP_OK) return rc_;
   }
   // look-ahead states / jacobians of the constraint chain on large models
-  if (ctx->d.Etot > 0 && ctx->d.nv > 6) {
+  if (ctx->d.Etot > 0 && (ctx->d.nv > 6 || ctx->model_h.ff)) {
     const Dims& d = ctx->d;
     const int64_t K = ctx->model_h.eq_advance;
     const size_t words = (size_t)(d.batch * d.T * (K * d.nx + (K > 1 ? K - 1 : 0) * d.n * d.n + d.emax * d.n));
@@ -888,7 +926,7 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   int rc;
   const int nv = (int)ctx->d.nv;
   if (nv <= 1) rc = run_linearize<1>(ctx, p, stages);
-  else if (nv <= 6) rc = run_linearize<6>(ctx, p, stages);
+  else if (nv <= 6 && !ctx->model_h.ff) rc = run_linearize<6>(ctx, p, stages);   // (the one-lane constraint chain of small models is vector-space only)
   else if (nv <= 38) rc = run_linearize<38>(ctx, p, stages);
   else rc = run_linearize<64>(ctx, p, stages);
   if (rc != DDP_HIP_OK) return rc;

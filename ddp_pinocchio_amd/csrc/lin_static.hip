@@ -1390,6 +1390,7 @@ __global__ __launch_bounds__(LBS) void lin_static_vcache_kernel(LinParams p, con
 }  // namespace
 
 int lin_static_supported(const DevModel& m) {
+  if (m.ff) return 0;            // compiled-in topologies are trees of 1-DoF joints
   if (topo_matches<TopoTalos38>(m)) return 1;
   if (topo_matches<TopoChain6>(m)) return 2;
   return 0;

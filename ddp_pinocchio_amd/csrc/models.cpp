@@ -89,7 +89,37 @@ void build_chain6(ddp_hip_model_storage* st, ddp_hip_model* out) {
   point_model(st, out);
 }
 
-void build_tree38(uint64_t seed, ddp_hip_model_storage* st, ddp_hip_model* out) {
+// free_flyer: the pelvis hangs from ONE SE(3) joint (q = [p, quaternion], nq = 39, nv = 38: the real Talos layout)
+// instead of 3 prismatic + 3 revolute joints (nq = nv = 38, a vector space)
+// the UR5-like chain on a floating base of 10 kg (nq = 13, nv = 12): the small Lie-group test model
+void build_chain6_ff(ddp_hip_model_storage* st, ddp_hip_model* out) {
+  ddp_hip_model tmp;
+  ddp_hip_model_storage arm;
+  memset(&arm, 0, sizeof(arm));
+  build_chain6(&arm, &tmp);
+  double Id[9];
+  set_identity(Id);
+  st->parent[0] = -1; st->jtype[0] = DDP_HIP_JOINT_FREEFLYER;
+  set_axis(st->axis, 'x'); set_identity(st->Rp);
+  st->mass_j[0] = 10.0; st->com[0] = 0.01; st->com[1] = -0.02; st->com[2] = 0.03;
+  box_inertia(10.0, 0.4, 0.3, 0.2, Id, st->Ic);
+  for (int i = 0; i < 6; ++i) {
+    st->parent[i + 1] = i; st->jtype[i + 1] = arm.jtype[i];
+    memcpy(st->axis + 3 * (i + 1), arm.axis + 3 * i, 3 * sizeof(double));
+    memcpy(st->Rp + 9 * (i + 1), arm.Rp + 9 * i, 9 * sizeof(double));
+    memcpy(st->pp + 3 * (i + 1), arm.pp + 3 * i, 3 * sizeof(double));
+    st->mass_j[i + 1] = arm.mass_j[i];
+    memcpy(st->com + 3 * (i + 1), arm.com + 3 * i, 3 * sizeof(double));
+    memcpy(st->Ic + 9 * (i + 1), arm.Ic + 9 * i, 9 * sizeof(double));
+  }
+  out->kind = DDP_HIP_MODEL_TREE;
+  out->nv = 12;
+  out->mass = out->length = 0;
+  out->gravity[0] = 0; out->gravity[1] = 0; out->gravity[2] = -9.81;
+  point_model(st, out);
+}
+
+void build_tree38(uint64_t seed, ddp_hip_model_storage* st, ddp_hip_model* out, bool free_flyer = false) {
   SplitMix64 rng{seed};
   int j = 0;
   auto add = [&](int parent, int type, char axis, double px, double py, double pz, bool massless) {
@@ -116,13 +146,19 @@ void build_tree38(uint64_t seed, ddp_hip_model_storage* st, ddp_hip_model* out) 
     return j++;
   };
   auto len = [&]() { return rng.uniform(0.05, 0.3); };
-  // floating base as 3 prismatic + 3 revolute joints; the first five carry no mass, the sixth is the pelvis
-  int b = add(-1, DDP_HIP_JOINT_PRISMATIC, 'x', 0, 0, 0, true);
-  b = add(b, DDP_HIP_JOINT_PRISMATIC, 'y', 0, 0, 0, true);
-  b = add(b, DDP_HIP_JOINT_PRISMATIC, 'z', 0, 0, 1.0, true);
-  b = add(b, DDP_HIP_JOINT_REVOLUTE, 'z', 0, 0, 0, true);
-  b = add(b, DDP_HIP_JOINT_REVOLUTE, 'y', 0, 0, 0, true);
-  int pelvis = add(b, DDP_HIP_JOINT_REVOLUTE, 'x', 0, 0, 0, false);
+  int pelvis;
+  if (free_flyer) {
+    pelvis = add(-1, DDP_HIP_JOINT_FREEFLYER, 'x', 0, 0, 0, false);
+    set_identity(st->Rp);                     // the placement of a free flyer IS its configuration
+  } else {
+    // floating base as 3 prismatic + 3 revolute joints; the first five carry no mass, the sixth is the pelvis
+    int b = add(-1, DDP_HIP_JOINT_PRISMATIC, 'x', 0, 0, 0, true);
+    b = add(b, DDP_HIP_JOINT_PRISMATIC, 'y', 0, 0, 0, true);
+    b = add(b, DDP_HIP_JOINT_PRISMATIC, 'z', 0, 0, 1.0, true);
+    b = add(b, DDP_HIP_JOINT_REVOLUTE, 'z', 0, 0, 0, true);
+    b = add(b, DDP_HIP_JOINT_REVOLUTE, 'y', 0, 0, 0, true);
+    pelvis = add(b, DDP_HIP_JOINT_REVOLUTE, 'x', 0, 0, 0, false);
+  }
   const char leg_axes[6] = {'z', 'x', 'y', 'y', 'y', 'x'};
   for (int side = 0; side < 2; ++side) {
     double sy = side == 0 ? 1.0 : -1.0;
@@ -140,7 +176,7 @@ void build_tree38(uint64_t seed, ddp_hip_model_storage* st, ddp_hip_model* out) 
   int head = add(torso, DDP_HIP_JOINT_REVOLUTE, 'y', 0, 0, len(), false);
   add(head, DDP_HIP_JOINT_REVOLUTE, 'z', 0, 0, len(), false);
   out->kind = DDP_HIP_MODEL_TREE;
-  out->nv = j;  // 38
+  out->nv = free_flyer ? j + 5 : j;  // 38 either way: 33 joints, six of the velocities belong to the root
   out->mass = out->length = 0;
   out->gravity[0] = 0; out->gravity[1] = 0; out->gravity[2] = -9.81;
   point_model(st, out);
@@ -166,6 +202,12 @@ extern "C" int ddp_hip_builtin_model(int which, uint64_t seed, ddp_hip_model_sto
       return DDP_HIP_OK;
     case DDP_HIP_BUILTIN_TREE38:
       build_tree38(seed, storage, out);
+      return DDP_HIP_OK;
+    case DDP_HIP_BUILTIN_CHAIN6_FF:
+      build_chain6_ff(storage, out);
+      return DDP_HIP_OK;
+    case DDP_HIP_BUILTIN_TREE38_FF:
+      build_tree38(seed, storage, out, true);
       return DDP_HIP_OK;
     default:
       return DDP_HIP_E_ARG;

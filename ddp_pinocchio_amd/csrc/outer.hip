@@ -11,11 +11,13 @@
 #include <vector>
 
 #include "internal.h"
+#include "lie.h"
 
 namespace {
 
 struct OuterParams {
   Dims d;
+  const DevModel* model;
   const int64_t* ne;
   const int64_t* Epre;
   const double *x, *lfx, *lx, *lu, *fx, *fu, *eq_val, *eq_x, *eq_u;
@@ -40,12 +42,37 @@ __global__ __launch_bounds__(OBS) void update_origin_kernel(OuterParams p, int w
   const double* jac = (which == 0 ? p.m_jac : p.f_jac) + R * n;
   const double* xn = p.x + ((int64_t)b * (T + 1) + t) * nx;
   __shared__ double dx[DDP_MAXJ * 2];
-  for (int i = threadIdx.x; i < n; i += OBS) dx[i] = xn[i] - org[i];
+  __shared__ double Jl[36];
+  const DevModel& mdl = *p.model;
+  if (mdl.ff) {
+    // x_new (-) origin on the group, and d(x_new (-) origin)/dx_new = blockdiag(Jlog6, I) (mat_seq_common.hpp:80-86,
+    // problem.hpp:414-439 with model_t::d_difference_dq_finish, pinocchio_model.ipp:306-321)
+    if (threadIdx.x == 0) {
+      lie::difference_x(mdl, org, xn, dx);
+      lie::se3_Jlog(dx, Jl);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += OBS) dx[i] = xn[i] - org[i];
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < r; i += OBS) {
     double s = 0.0;
     for (int l = 0; l < n; ++l) s += jac[i + (int64_t)l * r] * dx[l];
     val[i] += s;
+  }
+  if (mdl.ff) {
+    // jac <- jac * blockdiag(Jlog6, I): only the six leading columns change; one lane per row
+    double* jacw = const_cast<double*>(jac);
+    for (int i = threadIdx.x; i < r; i += OBS) {
+      double row[6], out[6];
+      for (int l = 0; l < 6; ++l) row[l] = jacw[i + (int64_t)l * r];
+      for (int c = 0; c < 6; ++c) {
+        double s = 0.0;
+        for (int l = 0; l < 6; ++l) s += row[l] * Jl[6 * l + c];
+        out[c] = s;
+      }
+      for (int c = 0; c < 6; ++c) jacw[i + (int64_t)c * r] = out[c];
+    }
   }
   for (int i = threadIdx.x; i < nx; i += OBS) org[i] = xn[i];
 }
@@ -74,7 +101,8 @@ __global__ __launch_bounds__(OBS) void optimality_kernel(OuterParams p) {
     const double* fu = p.fu + bt * n * m;
     const double* xt = p.x + ((int64_t)b * (T + 1) + t) * nx;
     const double* org = p.m_origin + bt * nx;
-    for (int i = tid; i < n; i += OBS) dxv[i] = xt[i] - org[i];
+    if (p.model->ff) { if (tid == 0) lie::difference_x(*p.model, org, xt, dxv); }
+    else for (int i = tid; i < n; i += OBS) dxv[i] = xt[i] - org[i];
     for (int i = tid; i < e; i += OBS) eqs[i] = eqv[i];
     __syncthreads();
     for (int i = tid; i < e; i += OBS) {          // pe = val + jac (x - origin)
@@ -161,6 +189,7 @@ __global__ __launch_bounds__(OBS) void update_multipliers_kernel(OuterParams p) 
 OuterParams make_params(ddp_hip_ctx* ctx) {
   OuterParams p{};
   p.d = ctx->d;
+  p.model = ctx->model_d;
   p.ne = ctx->ne_d;
   p.Epre = ctx->Epre_d;
   auto S = [&](int s) { return ctx->seq[s].ptr; };

@@ -5,6 +5,7 @@
 #pragma once
 
 #include "internal.h"
+#include "lie.h"
 
 namespace rbd {
 
@@ -170,17 +171,72 @@ __device__ __forceinline__ double pendulum_acc(const DevModel& m, double q, doub
 // vectors of the three tree passes live in a few slots (DevModel::slot_up / slot_down), allocated on the host so
 // that every sum is formed in the order of the textbook loop (a parent's accumulator starts from its own value when
 // its largest-index child contributes).
+// x = A^-1 b for a symmetric positive definite 6 x 6 in packed lower-triangle storage (Cholesky): the 6-DoF root joint
+__device__ __forceinline__ void sym6_solve(const double* A, const double* b, double* x) {
+  double L[21];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double d = A[sidx(k, k)];
+#pragma unroll
+    for (int j = 0; j < k; ++j) d -= L[sidx(k, j)] * L[sidx(k, j)];
+    d = sqrt(d);
+    L[sidx(k, k)] = d;
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      double t = A[sidx(i, k)];
+#pragma unroll
+      for (int j = 0; j < k; ++j) t -= L[sidx(i, j)] * L[sidx(k, j)];
+      L[sidx(i, k)] = t / d;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double t = b[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) t -= L[sidx(i, j)] * x[j];
+    x[i] = t / L[sidx(i, i)];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double t = x[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) t -= L[sidx(j, i)] * x[j];
+    x[i] = t / L[sidx(i, i)];
+  }
+}
+
+// placement of joint i from the whole configuration vector: a free-flyer root reads (p, quaternion), the others one scalar
+__device__ __forceinline__ void place(const DevModel& m, int i, const double* q, double* E, double* r) {
+  if (i == 0 && m.ff) {
+    double R[9];
+    lie::quat_to_R(q + 3, R);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) E[3 * k + l] = R[3 * l + k];
+    r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
+    return;
+  }
+  joint_placement(m, i, q[m.ff ? i + 6 : i], E, r);
+}
+
 template <int NJ>
 __device__ void aba_tree(const DevModel& m, const double* q, const double* v, const double* tau, double* qdd) {
-  const int N = m.nv;
+  const int N = m.nj;
+  const int ff = m.ff, vo = ff ? 5 : 0;           // joint i >= 1 of a free-flyer model uses v[i + 5] (and q[i + 6])
   double E[NJ][9], R[NJ][3], cb[NJ][6], pA0[NJ][6], U[NJ][6], Dinv[NJ], uu[NJ];
   double slot[8][6], islot[8][21];
+  double IAr[21], pAr[6];                         // articulated inertia / bias force of a 6-DoF root
   for (int i = 0; i < N; ++i) {
-    joint_placement(m, i, q[i], E[i], R[i]);
+    place(m, i, q, E[i], R[i]);
     const double* a = m.axis[i];
     double vJ[6] = {0, 0, 0, 0, 0, 0}, vel[6];
-    const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-    vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+    if (i == 0 && ff) {                           // S = identity on the body twist; v = [linear; angular]
+      vJ[0] = v[3]; vJ[1] = v[4]; vJ[2] = v[5]; vJ[3] = v[0]; vJ[4] = v[1]; vJ[5] = v[2];
+    } else {
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      vJ[o] = a[0] * v[i + vo]; vJ[o + 1] = a[1] * v[i + vo]; vJ[o + 2] = a[2] * v[i + vo];
+    }
     const int par = m.parent[i];
     if (par >= 0) xform_motion(E[i], R[i], slot[m.slot_down[par]], vel);
     else { for (int k = 0; k < 6; ++k) vel[k] = 0.0; }
@@ -203,11 +259,16 @@ __device__ void aba_tree(const DevModel& m, const double* q, const double* v, co
       for (int k = 0; k < 21; ++k) IA[k] = m.I6[i][k];
       for (int k = 0; k < 6; ++k) pAi[k] = pA0[i][k];
     }
+    if (i == 0 && ff) {                           // resolved in the last pass
+      for (int k = 0; k < 21; ++k) IAr[k] = IA[k];
+      for (int k = 0; k < 6; ++k) pAr[k] = pAi[k];
+      break;
+    }
     double d = 0, sp = 0;
     for (int r = 0; r < 6; ++r) U[i][r] = IA[sidx(r, o)] * a[0] + IA[sidx(r, o + 1)] * a[1] + IA[sidx(r, o + 2)] * a[2];
     for (int k = 0; k < 3; ++k) { d += a[k] * U[i][o + k]; sp += a[k] * pAi[o + k]; }
     Dinv[i] = 1.0 / d;
-    uu[i] = tau[i] - sp;
+    uu[i] = tau[i + vo] - sp;
     const int par = m.parent[i];
     if (par >= 0) {
       double Ia[21], pa[6], Iac[6], fp[6];
@@ -233,10 +294,20 @@ __device__ void aba_tree(const DevModel& m, const double* q, const double* v, co
       const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
       xform_motion(E[i], R[i], a0, ap);
     }
+    if (i == 0 && ff) {
+      // S = I: qdd_s = IA^-1 (tau_s - pA) - a' in the spatial ordering [angular; linear]; tau / qdd are ordered [linear; angular]
+      double rhs[6], qs[6];
+      for (int k = 0; k < 3; ++k) { rhs[k] = tau[3 + k] - pAr[k]; rhs[3 + k] = tau[k] - pAr[3 + k]; }
+      sym6_solve(IAr, rhs, qs);
+      for (int k = 0; k < 6; ++k) { ap[k] += cb[0][k]; qs[k] -= ap[k]; }
+      for (int k = 0; k < 3; ++k) { qdd[k] = qs[3 + k]; qdd[3 + k] = qs[k]; }
+      if (m.has_child[0]) { double* sl = slot[m.slot_down[0]]; for (int k = 0; k < 6; ++k) sl[k] = ap[k] + qs[k]; }
+      continue;
+    }
     double s = 0;
     for (int k = 0; k < 6; ++k) { ap[k] += cb[i][k]; s += U[i][k] * ap[k]; }
     const double qd = (uu[i] - s) * Dinv[i];
-    qdd[i] = qd;
+    qdd[i + vo] = qd;
     if (m.has_child[i]) {
       const double* a = m.axis[i];
       const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
@@ -259,6 +330,17 @@ __device__ void eval_f(const DevModel& m, const double* x, const double* u, doub
     return;
   }
   double acc[NJ];
+  if (m.ff) {
+    // q+ = q (+) dt v on SE(3) x R^(nv-6) (model.integrate, problem.hpp:452); x = [q(nv+1); v(nv)]
+    const int nq = nv + 1;
+    aba_tree<NJ>(m, x, x + nq, u, acc);
+    double dq[6];
+    for (int k = 0; k < 6; ++k) dq[k] = m.dt * x[nq + k];
+    lie::se3_integrate(x, dq, x_out);
+    for (int i = 6; i < nv; ++i) { const double vo = m.dt * x[nq + i]; x_out[i + 1] = x[i + 1] + vo; }
+    for (int i = 0; i < nv; ++i) x_out[nq + i] = x[nq + i] + acc[i] * m.dt;
+    return;
+  }
   aba_tree<NJ>(m, x, x + nv, u, acc);
   for (int i = 0; i < nv; ++i) {
     const double vo = m.dt * x[nv + i];
@@ -280,7 +362,7 @@ __device__ void frame_position(const DevModel& m, const double* q, double* p3, d
   for (int c = len - 1; c >= 0; --c) {
     const int i = chain[c];
     double E[9], r[3], Rc[9], t[3], nR[9];
-    joint_placement(m, i, q[i], E, r);
+    place(m, i, q, E, r);
     for (int k = 0; k < 3; ++k)
       for (int l = 0; l < 3; ++l) Rc[3 * k + l] = E[3 * l + k];
     mv3(oR, r, t);
@@ -288,12 +370,23 @@ __device__ void frame_position(const DevModel& m, const double* q, double* p3, d
     mm3(oR, Rc, nR);
     for (int k = 0; k < 9; ++k) oR[k] = nR[k];
     if (J) {
-      double aw[3];
-      mv3(oR, m.axis[i], aw);
-      if (m.jtype[i] == DDP_HIP_JOINT_REVOLUTE) {
-        const double lever[3] = {-op[0], -op[1], -op[2]};   // WORLD frame: lever arm to the world origin
-        cross3(aw, lever, J + 3 * i);
-      } else { J[3 * i] = aw[0]; J[3 * i + 1] = aw[1]; J[3 * i + 2] = aw[2]; }
+      const double lever[3] = {-op[0], -op[1], -op[2]};     // WORLD frame: lever arm to the world origin
+      if (i == 0 && m.ff) {
+        // free flyer: the columns of oMi.act(S), S = identity on [linear; angular] body twists
+        for (int cc = 0; cc < 3; ++cc) {
+          const double e[3] = {cc == 0 ? 1.0 : 0.0, cc == 1 ? 1.0 : 0.0, cc == 2 ? 1.0 : 0.0};
+          double aw[3];
+          mv3(oR, e, aw);
+          J[3 * cc] = aw[0]; J[3 * cc + 1] = aw[1]; J[3 * cc + 2] = aw[2];
+          cross3(aw, lever, J + 3 * (3 + cc));
+        }
+      } else {
+        const int vi = m.ff ? i + 5 : i;
+        double aw[3];
+        mv3(oR, m.axis[i], aw);
+        if (m.jtype[i] == DDP_HIP_JOINT_REVOLUTE) cross3(aw, lever, J + 3 * vi);
+        else { J[3 * vi] = aw[0]; J[3 * vi + 1] = aw[1]; J[3 * vi + 2] = aw[2]; }
+      }
     }
   }
   double t[3];

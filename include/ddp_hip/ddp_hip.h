@@ -60,15 +60,18 @@ enum {
 
 enum { DDP_HIP_MODEL_PENDULUM = 0, DDP_HIP_MODEL_TREE = 1 };
 enum { DDP_HIP_EQ_NONE = 0, DDP_HIP_EQ_CONFIG = 1, DDP_HIP_EQ_FRAME = 2 };
-enum { DDP_HIP_JOINT_REVOLUTE = 0, DDP_HIP_JOINT_PRISMATIC = 1 };
+/* FREEFLYER: joint 0 only (parent -1): an SE(3) joint, q = [p(3), quaternion x y z w], v = [linear(3), angular(3)] in the
+ * body frame (Pinocchio's JointModelFreeFlyer); the model then has nq = nv + 1 and nv - 5 joints */
+enum { DDP_HIP_JOINT_REVOLUTE = 0, DDP_HIP_JOINT_PRISMATIC = 1, DDP_HIP_JOINT_FREEFLYER = 2 };
 
 #define DDP_HIP_MAX_JOINTS 64
 
-/* Model concept (pinocchio_model.hpp:77-186, pendulum_model.hpp:10-133): a tree of 1-DoF joints
- * (nq == nv, the case FD mode 1 requires: problem.hpp:78-81) or the closed-form pendulum. */
+/* Model concept (pinocchio_model.hpp:77-186, pendulum_model.hpp:10-133): a tree of 1-DoF joints (nq == nv, the case FD
+ * mode 1 requires: problem.hpp:78-81), optionally hanging from a free-flyer root (a Lie-group configuration, nq = nv + 1:
+ * pinocchio_model.ipp:222-321), or the closed-form pendulum.  The per-joint arrays have nv entries, nv - 5 with a free flyer. */
 typedef struct ddp_hip_model {
   int32_t kind;
-  int32_t nv;
+  int32_t nv;                    /* velocity / tangent dimension */
   double mass, length;           /* pendulum: pendulum_model.hpp:24-26 (g = 9.81) */
   const int32_t* parent;         /* [nv], parent[i] < i, -1 = world */
   const int32_t* jtype;          /* [nv] DDP_HIP_JOINT_* */
@@ -260,7 +263,8 @@ int ddp_hip_model_aba_derivatives(ddp_hip_model_handle* h, const double* q, cons
 int ddp_hip_model_frame(ddp_hip_model_handle* h, int32_t joint, const double off[3], const double* q, double* p3, double* J);
 
 /* ---- built-in seeded model tables (no URDF exists offline: SURVEY.md D4, 8d) -------------- */
-enum { DDP_HIP_BUILTIN_PENDULUM = 0, DDP_HIP_BUILTIN_CHAIN6 = 1, DDP_HIP_BUILTIN_TREE38 = 2 };
+/* ..._FF: the same robots on a free-flyer root instead of a fixed base / 3 prismatic + 3 revolute base joints */
+enum { DDP_HIP_BUILTIN_PENDULUM = 0, DDP_HIP_BUILTIN_CHAIN6 = 1, DDP_HIP_BUILTIN_TREE38 = 2, DDP_HIP_BUILTIN_CHAIN6_FF = 3, DDP_HIP_BUILTIN_TREE38_FF = 4 };
 /* fills caller-provided arrays (sized for DDP_HIP_MAX_JOINTS) and points `out` at them */
 typedef struct ddp_hip_model_storage {
   int32_t parent[DDP_HIP_MAX_JOINTS];

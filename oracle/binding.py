@@ -76,6 +76,12 @@ def lib(path=None):
     L.orc_aba.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp]
     L.orc_rnea.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp]
     L.orc_crba.argtypes = [C.POINTER(OrcModel), _dp, _dp]
+    L.orc_model_nq.restype = C.c_int32
+    L.orc_model_nq.argtypes = [C.POINTER(OrcModel)]
+    L.orc_integrate.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp]
+    L.orc_difference.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp]
+    for _n in ("orc_d_integrate_dq", "orc_d_integrate_dv", "orc_d_difference_dq_start", "orc_d_difference_dq_finish"):
+        getattr(L, _n).argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp]
     L.orc_rnea_derivatives.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_aba_derivatives.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp, _dp, _dp]
     L.orc_frame_position.argtypes = [C.POINTER(OrcModel), C.c_int32, _dp, _dp, _dp]
@@ -132,7 +138,9 @@ class Oracle:
         self.L = lib(lib_path)
         self.nv = int(model.nv)
         self.T = int(T)
-        self.n, self.m, self.nx = 2 * self.nv, self.nv, 2 * self.nv
+        self.ff = int(model.kind) == 1 and len(np.atleast_1d(model.jtype)) > 0 and int(np.atleast_1d(model.jtype)[0]) == 2
+        self.nq = self.nv + 1 if self.ff else self.nv
+        self.n, self.m, self.nx = 2 * self.nv, self.nv, self.nq + self.nv
         self._keep = dict(
             parent=np.ascontiguousarray(model.parent, dtype=np.int32), jtype=np.ascontiguousarray(model.jtype, dtype=np.int32),
             axis=_f64(model.axis), Rp=_f64(model.Rp), pp=_f64(model.pp), mass_j=_f64(model.mass_j), com=_f64(model.com),
@@ -178,6 +186,36 @@ class Oracle:
         out = np.zeros((self.nv, self.nv))
         self.L.orc_crba(C.byref(self.model), _p(q), _p(out))
         return out.T.copy()  # column-major -> numpy
+
+    # ---- Lie-group configurations (pinocchio_model.ipp:222-321)
+    def integrate(self, q, v):
+        q, v = _f64(q), _f64(v)
+        out = np.zeros(self.nq)
+        self.L.orc_integrate(C.byref(self.model), _p(q), _p(v), _p(out))
+        return out
+
+    def difference(self, q0, q1):
+        q0, q1 = _f64(q0), _f64(q1)
+        out = np.zeros(self.nv)
+        self.L.orc_difference(C.byref(self.model), _p(q0), _p(q1), _p(out))
+        return out
+
+    def _lie_jac(self, name, a, b):
+        a, b = _f64(a), _f64(b)
+        out = np.zeros(self.nv * self.nv)
+        getattr(self.L, name)(C.byref(self.model), _p(a), _p(b), _p(out))
+        return out.reshape(self.nv, self.nv).T.copy()
+
+    def d_integrate_dq(self, q, v): return self._lie_jac("orc_d_integrate_dq", q, v)
+    def d_integrate_dv(self, q, v): return self._lie_jac("orc_d_integrate_dv", q, v)
+    def d_difference_dq_start(self, q0, q1): return self._lie_jac("orc_d_difference_dq_start", q0, q1)
+    def d_difference_dq_finish(self, q0, q1): return self._lie_jac("orc_d_difference_dq_finish", q0, q1)
+
+    def neutral(self):
+        q = np.zeros(self.nq)
+        if self.nq != self.nv:
+            q[6] = 1.0
+        return q
 
     def rnea_derivatives(self, q, v, a):
         """(dtau/dq, dtau/dv, M) of tau = RNEA(q, v, a), each nv x nv"""

@@ -99,7 +99,8 @@ static void llt_solve(int64_t m, const double* Lm, int64_t lda, int64_t c, doubl
 /* dims                                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
-int64_t orc_nx(const orc_problem* p) { return 2 * (int64_t)p->model.nv; }
+static int m_nq(const orc_model* m);
+int64_t orc_nx(const orc_problem* p) { return (int64_t)m_nq(&p->model) + p->model.nv; }
 int64_t orc_ndx(const orc_problem* p) { return 2 * (int64_t)p->model.nv; }
 int64_t orc_nu(const orc_problem* p) { return (int64_t)p->model.nv; }
 int64_t orc_ne_total(const orc_problem* p) {
@@ -145,6 +146,223 @@ static void rot_axis(const double* a, double q, double* R) {
   R[0] += 1.0; R[4] += 1.0; R[8] += 1.0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Lie-group configurations: a free-flyer root joint (SE(3); q = [p(3), quaternion x y z w],     */
+/* v = [linear(3), angular(3)] in the body frame: Pinocchio's JointModelFreeFlyer), what           */
+/* model_t::integrate / difference / d_integrate_dq,dv / d_difference_dq_start,finish              */
+/* (pinocchio_model.ipp:222-321) delegate to pinocchio::integrate / difference / dIntegrate /      */
+/* dDifference.  Pinocchio is absent: restated from the closed forms of the exponential and        */
+/* logarithm of SE(3) and their Jacobians (Murray-Li-Sastry; Barfoot, State Estimation for         */
+/* Robotics, eqs. 7.85-7.86 for the Q block).  Pinned by the reference's own property tests        */
+/* (test/pinocchio.cpp:17-57,59-100: tests/test_lie.py) and by mpmath differences.                  */
+/* Only joint 0 may be a free flyer (jtype ORC_JOINT_FREEFLYER, parent -1); then nq = nv + 1 and    */
+/* the other joints j >= 1 use q[j + 6], v[j + 5].                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static void inv6(const double* A, double* Ainv);
+static int m_ff(const orc_model* m) { return m->kind == ORC_MODEL_TREE && m->jtype && m->jtype[0] == ORC_JOINT_FREEFLYER; }
+static int m_nj(const orc_model* m) { return m_ff(m) ? m->nv - 5 : m->nv; }
+static int m_nq(const orc_model* m) { return m_ff(m) ? m->nv + 1 : m->nv; }
+static int m_qi(const orc_model* m, int j) { return m_ff(m) ? j + 6 : j; }   /* j >= 1 when ff */
+static int m_vi(const orc_model* m, int j) { return m_ff(m) ? j + 5 : j; }
+int32_t orc_model_nq(const orc_model* m) { return m_nq(m); }
+
+static void quat_to_R(const double* qt, double* R) {      /* x y z w, unit; row-major */
+  double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+static void quat_mul(const double* a, const double* b, double* c) {
+  double ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  c[0] = aw * bx + ax * bw + ay * bz - az * by;
+  c[1] = aw * by - ax * bz + ay * bw + az * bx;
+  c[2] = aw * bz + ax * by - ay * bx + az * bw;
+  c[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+/* coefficients of the SO(3) / SE(3) series in theta = |w|, with Taylor expansions near 0:
+ * a = sin t / t, b = (1 - cos t) / t^2, c = (t - sin t) / t^3, d = (1 - (t sin t) / (2 (1 - cos t))) / t^2 */
+static void so3_coeffs(double t2, double* a, double* b, double* c, double* d) {
+  if (t2 < 1e-8) {
+    *a = 1 - t2 / 6 + t2 * t2 / 120; *b = 0.5 - t2 / 24 + t2 * t2 / 720; *c = 1.0 / 6 - t2 / 120 + t2 * t2 / 5040;
+    *d = 1.0 / 12 + t2 / 720 + t2 * t2 / 30240;
+  } else {
+    double t = sqrt(t2), st = sin(t), ct = cos(t);
+    *a = st / t; *b = (1 - ct) / t2; *c = (t - st) / (t2 * t); *d = (1 - t * st / (2 * (1 - ct))) / t2;
+  }
+}
+/* quaternion of exp3(w) */
+static void quat_exp(const double* w, double* qt) {
+  double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], k, cw;
+  if (t2 < 1e-8) { k = 0.5 - t2 / 48; cw = 1 - t2 / 8 + t2 * t2 / 384; }
+  else { double t = sqrt(t2); k = sin(t / 2) / t; cw = cos(t / 2); }
+  qt[0] = k * w[0]; qt[1] = k * w[1]; qt[2] = k * w[2]; qt[3] = cw;
+}
+/* log3 of a unit quaternion (shortest rotation) */
+static void quat_log(const double* qin, double* w) {
+  double qt[4] = {qin[0], qin[1], qin[2], qin[3]};
+  if (qt[3] < 0) { qt[0] = -qt[0]; qt[1] = -qt[1]; qt[2] = -qt[2]; qt[3] = -qt[3]; }
+  double n2 = qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2], k;
+  if (n2 < 1e-16) k = 2.0 / qt[3] * (1 - n2 / (3 * qt[3] * qt[3]));
+  else { double nn = sqrt(n2); k = 2 * atan2(nn, qt[3]) / nn; }
+  w[0] = k * qt[0]; w[1] = k * qt[1]; w[2] = k * qt[2];
+}
+/* y = (I + alpha [w]x + beta [w]x^2) x */
+static void so3_apply(const double* w, double alpha, double beta, const double* x, double* y) {
+  double wx[3], wwx[3];
+  cross3(w, x, wx);
+  cross3(w, wx, wwx);
+  for (int k = 0; k < 3; ++k) y[k] = x[k] + alpha * wx[k] + beta * wwx[k];
+}
+/* SE(3): q' = q (+) nu, nu = (v, w) body twist [linear; angular] (pinocchio SpecialEuclideanOperation<3>::integrate) */
+static void se3_integrate(const double* q7, const double* nu, double* out7) {
+  double R[9], a, b, c, d, pe[3], Rpe[3], qe[4], qn[4];
+  const double* v = nu; const double* w = nu + 3;
+  double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  so3_coeffs(t2, &a, &b, &c, &d);
+  so3_apply(w, b, c, v, pe);                         /* V(w) v */
+  quat_to_R(q7 + 3, R);
+  mat3_vec(R, pe, Rpe);
+  for (int k = 0; k < 3; ++k) out7[k] = q7[k] + Rpe[k];
+  quat_exp(w, qe);
+  quat_mul(q7 + 3, qe, qn);
+  if (qn[0] * q7[3] + qn[1] * q7[4] + qn[2] * q7[5] + qn[3] * q7[6] < 0) for (int k = 0; k < 4; ++k) qn[k] = -qn[k];
+  double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+  for (int k = 0; k < 4; ++k) out7[3 + k] = qn[k] / nn;
+}
+/* nu = q1 (-) q0 = log6(M0^-1 M1) */
+static void se3_difference(const double* q0, const double* q1, double* nu) {
+  double R0[9], dp[3], rp[3], q0c[4] = {-q0[3], -q0[4], -q0[5], q0[6]}, qr[4], w[3], a, b, c, d;
+  quat_mul(q0c, q1 + 3, qr);
+  quat_log(qr, w);
+  quat_to_R(q0 + 3, R0);
+  for (int k = 0; k < 3; ++k) dp[k] = q1[k] - q0[k];
+  for (int k = 0; k < 3; ++k) rp[k] = R0[k] * dp[0] + R0[3 + k] * dp[1] + R0[6 + k] * dp[2];   /* R0^T dp */
+  so3_coeffs(w[0] * w[0] + w[1] * w[1] + w[2] * w[2], &a, &b, &c, &d);
+  so3_apply(w, -0.5, d, rp, nu);                     /* V(w)^-1 = I - 1/2 [w]x + d [w]x^2 */
+  nu[3] = w[0]; nu[4] = w[1]; nu[5] = w[2];
+}
+/* Jacobian of log6 at M = exp6(nu) w.r.t. a right (body) perturbation of M: d(q1 (-) q0)/d q1 in the tangent at q1
+ * (pinocchio dDifference ARG1 = Jlog6).  Row-major 6 x 6, rows / columns ordered [linear; angular]:
+ *   Jlog6 = [ Jr^-1(w)   -Jr^-1(w) Q Jr^-1(w) ;  0   Jr^-1(w) ],  Jr^-1(w) = I + 1/2 [w]x + d [w]x^2,  Q = Q_r(v, w) */
+static void se3_Jlog(const double* nu, double* J) {
+  const double* v = nu; const double* w = nu + 3;
+  double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], a, b, c, d;
+  so3_coeffs(t2, &a, &b, &c, &d);
+  double W[9], V[9], W2[9], Ji[9], Q[9], T1[9], T2[9], T3[9], T4[9];
+  skew(w, W); skew(v, V);
+  mat3_mul(W, W, W2);
+  for (int k = 0; k < 9; ++k) Ji[k] = 0.5 * W[k] + d * W2[k];
+  Ji[0] += 1; Ji[4] += 1; Ji[8] += 1;
+  /* Barfoot's Q_l(rho, phi); the right-perturbation version is Q_l(-rho, -phi) */
+  double c4, c5;   /* (1 - t^2/2 - cos t)/t^4 ,  (c4 - 3 (t - sin t - t^3/6)/t^5)/2 */
+  if (t2 < 1e-6) { c4 = -1.0 / 24 + t2 / 720 - t2 * t2 / 40320; c5 = 0.5 * (c4 - 3 * (-1.0 / 120 + t2 / 5040 - t2 * t2 / 362880)); }
+  else { double t = sqrt(t2); c4 = (1 - t2 / 2 - cos(t)) / (t2 * t2); c5 = 0.5 * (c4 - 3 * (t - sin(t) - t2 * t / 6) / (t2 * t2 * t)); }
+  double nW[9], nV[9], WV[9], VW[9], WVW[9], WWV[9], VWW[9], WVWW[9], WWVW[9];
+  for (int k = 0; k < 9; ++k) { nW[k] = -W[k]; nV[k] = -V[k]; }
+  mat3_mul(nW, nV, WV); mat3_mul(nV, nW, VW);
+  mat3_mul(WV, nW, WVW);
+  mat3_mul(nW, WV, WWV); mat3_mul(VW, nW, VWW);
+  mat3_mul(WVW, nW, WVWW); mat3_mul(nW, WVW, WWVW);
+  for (int k = 0; k < 9; ++k)
+    Q[k] = 0.5 * nV[k] + c * (WV[k] + VW[k] + WVW[k]) - c4 * (WWV[k] + VWW[k] - 3 * WVW[k]) - c5 * (WVWW[k] + WWVW[k]);
+  (void)T3; (void)T4; (void)a; (void)b;
+  mat3_mul(Ji, Q, T1); mat3_mul(T1, Ji, T2);
+  memset(J, 0, 36 * sizeof(double));
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { J[6 * i + j] = Ji[3 * i + j]; J[6 * (i + 3) + j + 3] = Ji[3 * i + j]; J[6 * i + j + 3] = -T2[3 * i + j]; }
+}
+
+/* model_t::integrate, pinocchio_model.ipp:222-236 */
+void orc_integrate(const orc_model* m, const double* q, const double* v, double* out_q) {
+  if (!m_ff(m)) { for (int i = 0; i < m->nv; ++i) out_q[i] = q[i] + v[i]; return; }
+  se3_integrate(q, v, out_q);
+  for (int j = 1; j < m_nj(m); ++j) out_q[j + 6] = q[j + 6] + v[j + 5];
+}
+/* model_t::difference, pinocchio_model.ipp:271-286: out_v = q_finish (-) q_start */
+void orc_difference(const orc_model* m, const double* q_start, const double* q_finish, double* out_v) {
+  if (!m_ff(m)) { for (int i = 0; i < m->nv; ++i) out_v[i] = q_finish[i] - q_start[i]; return; }
+  se3_difference(q_start, q_finish, out_v);
+  for (int j = 1; j < m_nj(m); ++j) out_v[j + 5] = q_finish[j + 6] - q_start[j + 6];
+}
+/* model_t::d_difference_dq_finish, pinocchio_model.ipp:306-321 (nv x nv column-major) */
+void orc_d_difference_dq_finish(const orc_model* m, const double* q_start, const double* q_finish, double* out) {
+  int nv = m->nv;
+  memset(out, 0, sizeof(double) * (size_t)nv * nv);
+  for (int i = 0; i < nv; ++i) out[i + (int64_t)i * nv] = 1.0;
+  if (!m_ff(m)) return;
+  double nu[6], J[36];
+  se3_difference(q_start, q_finish, nu);
+  se3_Jlog(nu, J);
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) out[i + (int64_t)j * nv] = J[6 * i + j];
+}
+/* model_t::d_difference_dq_start, pinocchio_model.ipp:288-304: -Jlog6(M) Ad(M^-1), M = M0^-1 M1 = exp6(nu);
+ * equivalently -Jl^-1(nu) = -Jlog6(-nu)... formed here as -Jlog6 evaluated at -nu transposed structure: the left Jacobian */
+void orc_d_difference_dq_start(const orc_model* m, const double* q_start, const double* q_finish, double* out) {
+  int nv = m->nv;
+  memset(out, 0, sizeof(double) * (size_t)nv * nv);
+  for (int i = 0; i < nv; ++i) out[i + (int64_t)i * nv] = -1.0;
+  if (!m_ff(m)) return;
+  /* d log6(M0^-1 M1)/d(M0 right perturbation) = -Jl^-1(nu), and Jl^-1(nu) = Jr^-1(-nu) */
+  double nu[6], J[36];
+  se3_difference(q_start, q_finish, nu);
+  for (int k = 0; k < 6; ++k) nu[k] = -nu[k];
+  se3_Jlog(nu, J);
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) out[i + (int64_t)j * nv] = -J[6 * i + j];
+}
+/* model_t::d_integrate_dq / d_integrate_dv, pinocchio_model.ipp:238-269: d(q (+) v)/dq = Ad(exp6(v))^-1 and
+ * d(q (+) v)/dv = Jr(v) = Jlog6(v)^-1, in the tangent at q (+) v */
+static void inv6(const double* A, double* Ainv) {   /* Gauss-Jordan with partial pivoting, row-major 6 x 6 */
+  double M[6][12];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { M[i][j] = A[6 * i + j]; M[i][6 + j] = i == j; }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r) if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+    if (piv != c) for (int j = 0; j < 12; ++j) { double t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
+    double dinv = 1.0 / M[c][c];
+    for (int j = 0; j < 12; ++j) M[c][j] *= dinv;
+    for (int r = 0; r < 6; ++r) if (r != c) { double f = M[r][c]; for (int j = 0; j < 12; ++j) M[r][j] -= f * M[c][j]; }
+  }
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ainv[6 * i + j] = M[i][6 + j];
+}
+void orc_d_integrate_dv(const orc_model* m, const double* q, const double* v, double* out) {
+  int nv = m->nv;
+  (void)q;
+  memset(out, 0, sizeof(double) * (size_t)nv * nv);
+  for (int i = 0; i < nv; ++i) out[i + (int64_t)i * nv] = 1.0;
+  if (!m_ff(m)) return;
+  double J[36], Ji[36];
+  se3_Jlog(v, J);
+  inv6(J, Ji);
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) out[i + (int64_t)j * nv] = Ji[6 * i + j];
+}
+void orc_d_integrate_dq(const orc_model* m, const double* q, const double* v, double* out) {
+  int nv = m->nv;
+  (void)q;
+  memset(out, 0, sizeof(double) * (size_t)nv * nv);
+  for (int i = 0; i < nv; ++i) out[i + (int64_t)i * nv] = 1.0;
+  if (!m_ff(m)) return;
+  /* Ad(exp6(v)^-1) for twists ordered [linear; angular]: [R^T, -R^T [p]x; 0, R^T] with (R, p) = exp6(v) */
+  double a, b, c, d, pe[3], qe[4], R[9], px[9], RtP[9], Rt[9];
+  const double* w = v + 3;
+  so3_coeffs(w[0] * w[0] + w[1] * w[1] + w[2] * w[2], &a, &b, &c, &d);
+  so3_apply(w, b, c, v, pe);
+  quat_exp(w, qe);
+  quat_to_R(qe, R);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[3 * i + j] = R[3 * j + i];
+  skew(pe, px);
+  mat3_mul(Rt, px, RtP);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      out[i + (int64_t)j * nv] = Rt[3 * i + j];
+      out[(i + 3) + (int64_t)(j + 3) * nv] = Rt[3 * i + j];
+      out[i + (int64_t)(j + 3) * nv] = -RtP[3 * i + j];
+      out[(i + 3) + (int64_t)j * nv] = 0.0;
+    }
+}
+
 /* joint i at position q: E = rotation parent->child coordinates, r = child origin in parent frame */
 static void joint_placement(const orc_model* m, int i, double q, double* E, double* r) {
   const double* Rp = m->Rp + 9 * i;
@@ -163,6 +381,18 @@ static void joint_placement(const orc_model* m, int i, double q, double* E, doub
   }
   for (int k = 0; k < 3; ++k)
     for (int l = 0; l < 3; ++l) E[3 * k + l] = Rc[3 * l + k];
+}
+/* placement of joint i from the whole configuration vector: a free-flyer root reads (p, quat), the others one scalar */
+static void place(const orc_model* m, int i, const double* q, double* E, double* r) {
+  if (i == 0 && m_ff(m)) {
+    double R[9];
+    quat_to_R(q + 3, R);                       /* world coords = R * body coords */
+    for (int k = 0; k < 3; ++k)
+      for (int l = 0; l < 3; ++l) E[3 * k + l] = R[3 * l + k];
+    r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
+    return;
+  }
+  joint_placement(m, i, q[m_qi(m, i)], E, r);
 }
 /* Pluecker motion transform X = [E 0; -E rx E] (RBDA eq. 2.24) */
 static void plucker(const double* E, const double* r, double* X) {
@@ -240,17 +470,21 @@ static void pendulum_aba(const orc_model* m, const double* q, const double* tau,
 
 void orc_aba(const orc_model* m, const double* q, const double* v, const double* tau, double* qdd) {
   if (m->kind == ORC_MODEL_PENDULUM) { pendulum_aba(m, q, tau, qdd); return; }
-  int N = m->nv;
+  int N = m_nj(m), ff = m_ff(m);
   double* X = dalloc(36 * N);  double* vel = dalloc(6 * N); double* cb = dalloc(6 * N);
   double* IA = dalloc(36 * N); double* pA = dalloc(6 * N);  double* U = dalloc(6 * N);
   double* D = dalloc(N);       double* uu = dalloc(N);      double* acc = dalloc(6 * N);
   double S[6], E[9], r[3], tmp6[6];
   for (int i = 0; i < N; ++i) {
-    joint_placement(m, i, q[i], E, r);
+    place(m, i, q, E, r);
     plucker(E, r, X + 36 * i);
-    motion_subspace(m, i, S);
     double vJ[6];
-    for (int k = 0; k < 6; ++k) vJ[k] = S[k] * v[i];
+    if (i == 0 && ff) {                        /* S = identity on the body twist; v = [linear; angular] */
+      for (int k = 0; k < 3; ++k) { vJ[k] = v[3 + k]; vJ[3 + k] = v[k]; }
+    } else {
+      motion_subspace(m, i, S);
+      for (int k = 0; k < 6; ++k) vJ[k] = S[k] * v[m_vi(m, i)];
+    }
     if (m->parent[i] >= 0) mat6_vec(X + 36 * i, vel + 6 * m->parent[i], vel + 6 * i);
     else memset(vel + 6 * i, 0, 6 * sizeof(double));
     for (int k = 0; k < 6; ++k) vel[6 * i + k] += vJ[k];
@@ -260,12 +494,13 @@ void orc_aba(const orc_model* m, const double* q, const double* v, const double*
     crf(vel + 6 * i, tmp6, pA + 6 * i);
   }
   for (int i = N - 1; i >= 0; --i) {
+    if (i == 0 && ff) break;                   /* the 6-DoF root is resolved in the last pass */
     motion_subspace(m, i, S);
     mat6_vec(IA + 36 * i, S, U + 6 * i);
     double d = 0, sp = 0;
     for (int k = 0; k < 6; ++k) { d += S[k] * U[6 * i + k]; sp += S[k] * pA[6 * i + k]; }
     D[i] = d;
-    uu[i] = tau[i] - sp;
+    uu[i] = tau[m_vi(m, i)] - sp;
     int par = m->parent[i];
     if (par >= 0) {
       double Ia[36], pa[6], Iac[6], XtIa[36], XtIaX[36];
@@ -300,11 +535,21 @@ void orc_aba(const orc_model* m, const double* q, const double* v, const double*
       mat6_vec(X + 36 * i, a0, ap);
     }
     for (int k = 0; k < 6; ++k) ap[k] += cb[6 * i + k];
+    if (i == 0 && ff) {
+      /* S = I: qdd_s = IA^-1 (tau_s - pA) - a', spatial ordering [angular; linear]; tau, qdd ordered [linear; angular] */
+      double rhs[6], Ainv[36], qs[6];
+      for (int k = 0; k < 3; ++k) { rhs[k] = tau[3 + k] - pA[k]; rhs[3 + k] = tau[k] - pA[3 + k]; }
+      inv6(IA, Ainv);
+      mat6_vec(Ainv, rhs, qs);
+      for (int k = 0; k < 6; ++k) { qs[k] -= ap[k]; acc[k] = ap[k] + qs[k]; }
+      for (int k = 0; k < 3; ++k) { qdd[k] = qs[3 + k]; qdd[3 + k] = qs[k]; }
+      continue;
+    }
     double s = 0;
     for (int k = 0; k < 6; ++k) s += U[6 * i + k] * ap[k];
-    qdd[i] = (uu[i] - s) / D[i];
+    qdd[m_vi(m, i)] = (uu[i] - s) / D[i];
     motion_subspace(m, i, S);
-    for (int k = 0; k < 6; ++k) acc[6 * i + k] = ap[k] + S[k] * qdd[i];
+    for (int k = 0; k < 6; ++k) acc[6 * i + k] = ap[k] + S[k] * qdd[m_vi(m, i)];
   }
   free(X); free(vel); free(cb); free(IA); free(pA); free(U); free(D); free(uu); free(acc);
 }
@@ -315,15 +560,19 @@ void orc_rnea(const orc_model* m, const double* q, const double* v, const double
     tau[0] = m->mass * (a[0] + 9.81 / m->length * sin(q[0]));
     return;
   }
-  int N = m->nv;
+  int N = m_nj(m), ff = m_ff(m);
   double* X = dalloc(36 * N); double* vel = dalloc(6 * N); double* acc = dalloc(6 * N); double* f = dalloc(6 * N);
   double S[6], E[9], r[3], I6[36], t1[6], t2[6];
   for (int i = 0; i < N; ++i) {
-    joint_placement(m, i, q[i], E, r);
+    place(m, i, q, E, r);
     plucker(E, r, X + 36 * i);
-    motion_subspace(m, i, S);
-    double vJ[6];
-    for (int k = 0; k < 6; ++k) vJ[k] = S[k] * v[i];
+    double vJ[6], aJ[6];
+    if (i == 0 && ff) {
+      for (int k = 0; k < 3; ++k) { vJ[k] = v[3 + k]; vJ[3 + k] = v[k]; aJ[k] = a[3 + k]; aJ[3 + k] = a[k]; }
+    } else {
+      motion_subspace(m, i, S);
+      for (int k = 0; k < 6; ++k) { vJ[k] = S[k] * v[m_vi(m, i)]; aJ[k] = S[k] * a[m_vi(m, i)]; }
+    }
     int par = m->parent[i];
     if (par >= 0) {
       mat6_vec(X + 36 * i, vel + 6 * par, vel + 6 * i);
@@ -335,7 +584,7 @@ void orc_rnea(const orc_model* m, const double* q, const double* v, const double
     }
     for (int k = 0; k < 6; ++k) vel[6 * i + k] += vJ[k];
     crm(vel + 6 * i, vJ, t1);
-    for (int k = 0; k < 6; ++k) acc[6 * i + k] += S[k] * a[i] + t1[k];
+    for (int k = 0; k < 6; ++k) acc[6 * i + k] += aJ[k] + t1[k];
     body_inertia(m, i, I6);
     mat6_vec(I6, acc + 6 * i, t1);
     mat6_vec(I6, vel + 6 * i, t2);
@@ -343,10 +592,14 @@ void orc_rnea(const orc_model* m, const double* q, const double* v, const double
     for (int k = 0; k < 6; ++k) f[6 * i + k] += t1[k];
   }
   for (int i = N - 1; i >= 0; --i) {
-    motion_subspace(m, i, S);
-    double s = 0;
-    for (int k = 0; k < 6; ++k) s += S[k] * f[6 * i + k];
-    tau[i] = s;
+    if (i == 0 && ff) {
+      for (int k = 0; k < 3; ++k) { tau[k] = f[3 + k]; tau[3 + k] = f[k]; }
+    } else {
+      motion_subspace(m, i, S);
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += S[k] * f[6 * i + k];
+      tau[m_vi(m, i)] = s;
+    }
     int par = m->parent[i];
     if (par >= 0) {
       mat6_tvec(X + 36 * i, f + 6 * i, t1);
@@ -372,9 +625,9 @@ void orc_crba(const orc_model* m, const double* q, double* M) {
 
 /* world placement of every joint frame: oR (row-major, world coords = oR * joint coords), op */
 static void forward_kinematics(const orc_model* m, const double* q, double* oR, double* op) {
-  for (int i = 0; i < m->nv; ++i) {
+  for (int i = 0; i < m_nj(m); ++i) {
     double E[9], r[3], Rc[9];
-    joint_placement(m, i, q[i], E, r);
+    place(m, i, q, E, r);
     for (int k = 0; k < 3; ++k)
       for (int l = 0; l < 3; ++l) Rc[3 * k + l] = E[3 * l + k];
     int par = m->parent[i];
@@ -392,7 +645,7 @@ static void forward_kinematics(const orc_model* m, const double* q, double* oR, 
 
 /* model_t::frame_coordinates, pinocchio_model.ipp:418-430 (translation of oMf) */
 void orc_frame_position(const orc_model* m, int32_t joint, const double* off, const double* q, double* p3) {
-  int N = m->nv;
+  int N = m_nj(m);
   double* oR = dalloc(9 * N); double* op = dalloc(3 * N);
   double t[3];
   forward_kinematics(m, q, oR, op);
@@ -406,24 +659,33 @@ void orc_frame_position(const orc_model* m, int32_t joint, const double* off, co
  * coincides with the WORLD ORIGIN, not of the frame origin (reference quirk kept as is). */
 void orc_frame_jacobian(const orc_model* m, int32_t joint, const double* off, const double* q,
                         int world_aligned, double* J) {
-  int N = m->nv;
+  int N = m_nj(m);
   double* oR = dalloc(9 * N); double* op = dalloc(3 * N);
   double p[3], t[3];
   forward_kinematics(m, q, oR, op);
   mat3_vec(oR + 9 * joint, off, t);
   for (int k = 0; k < 3; ++k) p[k] = op[3 * joint + k] + t[k];
-  memset(J, 0, sizeof(double) * 3 * (size_t)N);
+  memset(J, 0, sizeof(double) * 3 * (size_t)m->nv);
   for (int j = joint; j >= 0; j = m->parent[j]) {
+    double lever[3];
+    for (int k = 0; k < 3; ++k) lever[k] = (world_aligned ? p[k] : 0.0) - op[3 * j + k];
+    if (j == 0 && m_ff(m)) {
+      /* free flyer: columns of oMi.act(S), S = identity on [linear; angular] body twists */
+      for (int c = 0; c < 3; ++c) {
+        double e[3] = {0, 0, 0}, aw[3], col[3];
+        e[c] = 1.0;
+        mat3_vec(oR, e, aw);
+        for (int k = 0; k < 3; ++k) J[k + 3 * c] = aw[k];                 /* linear direction c */
+        cross3(aw, lever, col);
+        for (int k = 0; k < 3; ++k) J[k + 3 * (3 + c)] = col[k];           /* angular direction c */
+      }
+      continue;
+    }
     double aw[3], col[3];
     mat3_vec(oR + 9 * j, m->axis + 3 * j, aw);
-    if (m->jtype[j] == ORC_JOINT_REVOLUTE) {
-      double lever[3];
-      for (int k = 0; k < 3; ++k) lever[k] = (world_aligned ? p[k] : 0.0) - op[3 * j + k];
-      cross3(aw, lever, col);
-    } else {
-      col[0] = aw[0]; col[1] = aw[1]; col[2] = aw[2];
-    }
-    for (int k = 0; k < 3; ++k) J[k + 3 * j] = col[k];
+    if (m->jtype[j] == ORC_JOINT_REVOLUTE) cross3(aw, lever, col);
+    else { col[0] = aw[0]; col[1] = aw[1]; col[2] = aw[2]; }
+    for (int k = 0; k < 3; ++k) J[k + 3 * m_vi(m, j)] = col[k];
   }
   free(oR); free(op);
 }
@@ -593,14 +855,27 @@ void orc_aba_derivatives(const orc_model* m, const double* q, const double* v, c
 /* dynamics_t : problem.hpp:343-525                                                            */
 /* ------------------------------------------------------------------------------------------ */
 
+/* dynamics_t::integrate_x (problem.hpp:395-401): x (+) dx = (q (+) dx_q, v + dx_v);  difference_out for states
+ * (problem.hpp:403-412): (q1 (-) q0, v1 - v0) */
+static void integrate_x(const orc_problem* p, const double* x, const double* dx, double* out) {
+  int nv = p->model.nv, nq = m_nq(&p->model);
+  orc_integrate(&p->model, x, dx, out);
+  for (int i = 0; i < nv; ++i) out[nq + i] = x[nq + i] + dx[nv + i];
+}
+static void difference_x(const orc_problem* p, const double* x0, const double* x1, double* out) {
+  int nv = p->model.nv, nq = m_nq(&p->model);
+  orc_difference(&p->model, x0, x1, out);
+  for (int i = 0; i < nv; ++i) out[nv + i] = x1[nq + i] - x0[nq + i];
+}
+
 /* dynamics_t::eval_to, problem.hpp:441-461 (semi-implicit Euler) */
 void orc_eval_f(const orc_problem* p, const double* x, const double* u, double* x_out) {
-  int nv = p->model.nv;
-  const double* q = x; const double* v = x + nv;
-  double* q_out = x_out; double* v_out = x_out + nv;
+  int nv = p->model.nv, nq = m_nq(&p->model);
+  const double* q = x; const double* v = x + nq;
+  double* q_out = x_out; double* v_out = x_out + nq;
   double* acc = dalloc(nv);
   for (int i = 0; i < nv; ++i) v_out[i] = p->dt * v[i];
-  for (int i = 0; i < nv; ++i) q_out[i] = q[i] + v_out[i];   /* model.integrate, vector space */
+  orc_integrate(&p->model, q, v_out, q_out);                  /* model.integrate (problem.hpp:452) */
   orc_aba(&p->model, q, v, u, acc);
   for (int i = 0; i < nv; ++i) v_out[i] = v[i] + acc[i] * p->dt;
   free(acc);
@@ -628,7 +903,7 @@ void orc_first_order_f(const orc_problem* p, const double* x, const double* u, d
     fu[1] = at * p->dt;
     return;
   }
-  if (!p->first_order_fd) {
+  if (!p->first_order_fd && !m_ff(&p->model)) {
     /* problem.hpp:463-503 with d_dynamics_aba (:495): fx = [dInt_dq, dt dInt_dv; dt da/dq, I + dt da/dv], fu = [0; dt da/dtau];
      * on a vector space d_integrate_dq = d_integrate_dv = I (pendulum_model.hpp:64-84 does the same) */
     double* dq = dalloc((int64_t)nv * nv); double* dv = dalloc((int64_t)nv * nv); double* dt_ = dalloc((int64_t)nv * nv);
@@ -648,16 +923,18 @@ void orc_first_order_f(const orc_problem* p, const double* x, const double* u, d
     return;
   }
   double eps = sqrt(DBL_EPSILON);
-  double* xp = dalloc(n); double* up = dalloc(m); double* fp = dalloc(n);
+  int64_t nx = orc_nx(p);
+  double* xp = dalloc(nx); double* up = dalloc(m); double* fp = dalloc(nx); double* dx = dzalloc(n); double* df = dalloc(n);
   for (int64_t j = 0; j < n + m; ++j) {
-    memcpy(xp, x, sizeof(double) * (size_t)n);
+    memcpy(xp, x, sizeof(double) * (size_t)nx);
     memcpy(up, u, sizeof(double) * (size_t)m);
-    if (j < n) xp[j] = x[j] + eps; else up[j - n] = u[j - n] + eps;
+    if (j < n) { dx[j] = eps; integrate_x(p, x, dx, xp); dx[j] = 0.0; } else up[j - n] = u[j - n] + eps;
     orc_eval_f(p, xp, up, fp);
+    difference_x(p, f, fp, df);                               /* difference_out */
     double* col = (j < n) ? fx + j * n : fu + (j - n) * n;
-    for (int64_t k = 0; k < n; ++k) col[k] = (fp[k] - f[k]) / eps;
+    for (int64_t k = 0; k < n; ++k) col[k] = df[k] / eps;
   }
-  free(xp); free(up); free(fp);
+  free(xp); free(up); free(fp); free(dx); free(df);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -696,7 +973,7 @@ static void eq_base_first_order(const orc_problem* p, int64_t t, const double* x
     double* J = dalloc(3 * nv);
     orc_frame_jacobian(&p->model, p->frame_joint, p->frame_off, x, 0, J);
     for (int j = 0; j < nv; ++j)
-      for (int64_t i = 0; i < e; ++i) out_x[i + j * e] = J[i + 3 * j];
+      for (int64_t i = 0; i < e; ++i) out_x[i + j * e] = J[i + 3 * j];   /* columns in tangent (v) order */
     free(J);
   }
 }
@@ -765,15 +1042,16 @@ static void fd_second_order_1(const fd_fn* f, const double* x, const double* u, 
   int64_t o = f->o, n = orc_ndx(f->p), m = orc_nu(f->p);
   fn_first_order(f, x, u, ox, ou, out);
   if (o == 0) return;
-  double* fx_ = dalloc(o * n); double* fu_ = dalloc(o * m); double* out_ = dalloc(o);
-  double* x_ = dalloc(n); double* u_ = dalloc(m); double* dx = dzalloc(n); double* du = dzalloc(m);
+  int64_t nx_ = orc_nx(f->p);
+  double* fx_ = dalloc(o * n); double* fu_ = dalloc(o * m); double* out_ = dalloc(o > nx_ ? o : nx_);
+  double* x_ = dalloc(nx_); double* u_ = dalloc(m); double* dx = dzalloc(n); double* du = dzalloc(m);
   double eps = sqrt(DBL_EPSILON);
   for (int64_t i = 0; i < n + m; ++i) {
     int at_x = i < n;
     int64_t idx = at_x ? i : i - n;
     double* in_var = at_x ? &dx[idx] : &du[idx];
     *in_var = eps;
-    for (int64_t k = 0; k < n; ++k) x_[k] = x[k] + dx[k];  /* integrate_x, vector space */
+    integrate_x(f->p, x, dx, x_);                          /* integrate_x */
     for (int64_t k = 0; k < m; ++k) u_[k] = u[k] + du[k];  /* integrate_u, problem.hpp:403 */
     fn_first_order(f, x_, u_, fx_, fu_, out_);
     if (at_x) {
@@ -797,8 +1075,10 @@ static void fd_second_order_2(const fd_fn* f, const double* x, const double* u, 
   fn_first_order(f, x, u, ox, ou, out);
   if (o == 0) return;
   const double* f0 = out;
-  double* f1 = dzalloc(o); double* df = dzalloc(o);
-  double* x1 = dalloc(n); double* u1 = dalloc(m); double* dx = dzalloc(n); double* du = dzalloc(m);
+  int64_t nx_ = orc_nx(f->p);
+  int lie = !f->is_eq;                                   /* the dynamics' output is a state: difference_out is (-) on the group */
+  double* f1 = dzalloc(o > nx_ ? o : nx_); double* df = dzalloc(o);
+  double* x1 = dalloc(nx_); double* u1 = dalloc(m); double* dx = dzalloc(n); double* du = dzalloc(m);
   double eps = sqrt(sqrt(DBL_EPSILON));
   double eps2 = eps * eps;
   /* diagonal, :192-222 */
@@ -810,10 +1090,11 @@ static void fd_second_order_2(const fd_fn* f, const double* x, const double* u, 
     double* tensor = at_x ? oxx : ouu;
     int64_t L = at_x ? n : m;
     *in_var = eps;
-    for (int64_t k = 0; k < n; ++k) x1[k] = x[k] + dx[k];
+    integrate_x(f->p, x, dx, x1);
     for (int64_t k = 0; k < m; ++k) u1[k] = u[k] + du[k];
     fn_eval(f, x1, u1, f1);
-    for (int64_t k = 0; k < o; ++k) df[k] = f1[k] - f0[k];   /* difference_out */
+    if (lie) difference_x(f->p, f0, f1, df);                 /* difference_out (problem.hpp:206) */
+    else for (int64_t k = 0; k < o; ++k) df[k] = f1[k] - f0[k];
     for (int64_t k = 0; k < o; ++k) df[k] -= eps * f_col[k];
     for (int64_t k = 0; k < o; ++k) df[k] *= 2;
     for (int64_t k = 0; k < o; ++k) tensor[TIDX(k, idx, idx, o, L)] = df[k] / eps2;
@@ -839,10 +1120,11 @@ static void fd_second_order_2(const fd_fn* f, const double* x, const double* u, 
       if (at_x_1) { if (at_x_2) { tensor = oxx; L = n; } else { tensor = oux; L = m; } }
       else { tensor = ouu; L = m; }
       *in_var_2 = eps;
-      for (int64_t k = 0; k < n; ++k) x1[k] = x[k] + dx[k];
+      integrate_x(f->p, x, dx, x1);
       for (int64_t k = 0; k < m; ++k) u1[k] = u[k] + du[k];
       fn_eval(f, x1, u1, f1);
-      for (int64_t k = 0; k < o; ++k) df[k] = f1[k] - f0[k];
+      if (lie) difference_x(f->p, f0, f1, df);               /* difference_out (problem.hpp:268) */
+      else for (int64_t k = 0; k < o; ++k) df[k] = f1[k] - f0[k];
       for (int64_t k = 0; k < o; ++k) df[k] -= eps * f_col_1[k];
       for (int64_t k = 0; k < o; ++k) df[k] -= eps * f_col_2[k];
       for (int64_t k = 0; k < o; ++k) df[k] *= 2;
@@ -929,7 +1211,7 @@ void orc_cost_seq_aug(const orc_problem* p, const double* xs, const double* us, 
     if (e > 0) {
       orc_eval_eq(p, t, x, u, ce);
       /* affine proxy operator(), mat_seq_common.hpp:105-115 */
-      for (int64_t i = 0; i < n; ++i) dxv[i] = x[i] - mults->origin[t * nx + i];
+      difference_x(p, mults->origin + t * nx, x, dxv);               /* x (-) origin */
       for (int64_t i = 0; i < e; ++i) pe[i] = mults->val[E + i];
       gemv_n_add(e, n, mults->jac + E * n, e, dxv, pe);
       for (int64_t i = 0; i < e; ++i) { dot += pe[i] * ce[i]; sq += ce[i] * ce[i]; }
@@ -1081,7 +1363,7 @@ static void fwd_rollout(const orc_problem* p, double step, double* xs_new, doubl
     const double* xo = xs_old + t * nx;
     double* xn = xs_new + t * nx;
     double* un = us_new + t * m;
-    for (int64_t i = 0; i < n; ++i) tmp[i] = xn[i] - xo[i];                          /* :45 difference(out, old, new) */
+    difference_x(p, xo, xn, tmp);                                                    /* :45 difference(out, old, new) */
     for (int64_t i = 0; i < m; ++i) un[i] = us_old[t * m + i] + step * fb->val[t * m + i]; /* :47-48 */
     {
       const double* K = fb->jac + t * m * n;
@@ -1140,9 +1422,24 @@ void orc_update_origin(const orc_problem* p, orc_affine* a, const int64_t* rows,
   int64_t R = 0;
   for (int64_t t = 0; t < T; ++t) {
     int64_t r = rows[t];
-    for (int64_t i = 0; i < n; ++i) tmp[i] = xs_new[t * nx + i] - a->origin[t * nx + i];
+    difference_x(p, a->origin + t * nx, xs_new + t * nx, tmp);
     gemv_n_add(r, n, a->jac + R * n, r, tmp, a->val + R);
-    /* jac = jac * d_difference_dfinish = jac * I on a vector space (problem.hpp:414-439) */
+    /* jac = jac * d_difference_dfinish(origin, x_new) (mat_seq_common.hpp:80-86, problem.hpp:414-439): the identity on a
+     * vector space; with a free-flyer root its leading 6 x 6 block is Jlog6 */
+    if (m_ff(&p->model) && r > 0) {
+      int nv = p->model.nv;
+      double* Dq = dalloc((int64_t)nv * nv); double* nj = dzalloc(r * 6);
+      orc_d_difference_dq_finish(&p->model, a->origin + t * nx, xs_new + t * nx, Dq);
+      double* jac = a->jac + R * n;
+      for (int64_t c = 0; c < 6; ++c)
+        for (int64_t i = 0; i < r; ++i) {
+          double s_ = 0;
+          for (int64_t l = 0; l < 6; ++l) s_ += jac[i + l * r] * Dq[l + c * nv];
+          nj[i + c * r] = s_;
+        }
+      memcpy(jac, nj, sizeof(double) * (size_t)(r * 6));
+      free(Dq); free(nj);
+    }
     memcpy(a->origin + t * nx, xs_new + t * nx, sizeof(double) * (size_t)nx);
     R += r;
   }
@@ -1174,7 +1471,7 @@ double orc_optimality_obj(const orc_problem* p, const double* xs, const orc_affi
     E -= e;
     const double* eqv = d->eq_val + E; const double* eqx = d->eq_x + E * n; const double* equ = d->eq_u + E * m;
     const double* fx = d->fx + t * n * n; const double* fu = d->fu + t * n * m;
-    for (int64_t i = 0; i < n; ++i) dxv[i] = xs[t * nx + i] - mults->origin[t * nx + i];
+    difference_x(p, mults->origin + t * nx, xs + t * nx, dxv);
     for (int64_t i = 0; i < e; ++i) pe[i] = mults->val[E + i];
     gemv_n_add(e, n, mults->jac + E * n, e, dxv, pe);
     memcpy(lu, d->lu + t * m, sizeof(double) * (size_t)m);

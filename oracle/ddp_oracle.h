@@ -30,7 +30,7 @@ extern "C" {
 
 enum { ORC_MODEL_PENDULUM = 0, ORC_MODEL_TREE = 1 };
 enum { ORC_EQ_NONE = 0, ORC_EQ_CONFIG = 1, ORC_EQ_FRAME = 2 };
-enum { ORC_JOINT_REVOLUTE = 0, ORC_JOINT_PRISMATIC = 1 };
+enum { ORC_JOINT_REVOLUTE = 0, ORC_JOINT_PRISMATIC = 1, ORC_JOINT_FREEFLYER = 2 /* joint 0 only: SE(3), q = [p, quat xyzw], v = [lin, ang] body frame */ };
 
 /* Model concept: include/ddp/pinocchio_model.hpp:77-186, include/ddp/pendulum_model.hpp:10-133.
  * Only vector-space configurations (nq == nv, all joints 1-DoF) are restated: the reference's
@@ -102,6 +102,15 @@ void orc_frame_position(const orc_model* m, int32_t joint, const double* off, co
  * (pinocchio_model.ipp:458-461); world_aligned != 0 gives d(position)/dq instead */
 void orc_frame_jacobian(const orc_model* m, int32_t joint, const double* off, const double* q,
                         int world_aligned, double* J /* 3 x nv col-major */);
+
+/* ---- Lie-group configurations (pinocchio_model.ipp:222-321); nq = nv + 1 with a free-flyer root, else nq = nv ---- */
+int32_t orc_model_nq(const orc_model* m);
+void orc_integrate(const orc_model* m, const double* q, const double* v, double* out_q);
+void orc_difference(const orc_model* m, const double* q_start, const double* q_finish, double* out_v);
+void orc_d_integrate_dq(const orc_model* m, const double* q, const double* v, double* out /* nv x nv col-major */);
+void orc_d_integrate_dv(const orc_model* m, const double* q, const double* v, double* out);
+void orc_d_difference_dq_start(const orc_model* m, const double* q_start, const double* q_finish, double* out);
+void orc_d_difference_dq_finish(const orc_model* m, const double* q_start, const double* q_finish, double* out);
 
 /* ---- dynamics / constraints -------------------------------------------------------------- */
 void orc_eval_f(const orc_problem* p, const double* x, const double* u, double* x_out);

@@ -30,6 +30,22 @@ def make(name, T, batch=1, fd_mode=2, seed=1, first_order_fd=None, target=None):
         model = capi.BuiltinModel(capi.BUILTIN_TREE38, seed)
         ne = np.full(T, 38, dtype=np.int64)
         kw = dict(eq_kind=capi.EQ_CONFIG, eq_advance=2, ne=ne, eq_target=np.zeros(38 * T))
+    elif name == "chain6ff":      # the UR5-like arm on a free-flyer base (nq = 13, nv = 12): the small Lie-group model
+        model = capi.BuiltinModel(capi.BUILTIN_CHAIN6_FF)
+        kw = dict(eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))
+    elif name == "chain6ff_frame":  # ... with the 3-row frame translation of test/pinocchio_spatial_eq_ddp.cpp at t = T-2
+        model = capi.BuiltinModel(capi.BUILTIN_CHAIN6_FF)
+        ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 3
+        kw = dict(eq_kind=capi.EQ_FRAME, eq_advance=2, ne=ne, eq_target=np.array([0.3, 0.2, 0.4]), frame_joint=6,
+                  frame_off=(0.0, 0.0, 0.0823))
+    elif name == "tree38ff":      # the Talos-like tree on a free-flyer root: nq = 39, nv = 38 (the real Talos layout)
+        model = capi.BuiltinModel(capi.BUILTIN_TREE38_FF, seed)
+        kw = dict(eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))
+    elif name == "tree38ff_frame":  # BASELINE config 5 as worded: free-floating base + frame equality constraint
+        model = capi.BuiltinModel(capi.BUILTIN_TREE38_FF, seed)
+        ne = np.zeros(T, dtype=np.int64); ne[T - 2] = 3
+        kw = dict(eq_kind=capi.EQ_FRAME, eq_advance=2, ne=ne, eq_target=np.array([0.4, -0.1, 0.9]), frame_joint=22,
+                  frame_off=(0.0, 0.0, 0.1))
     elif name == "tree38":        # Talos-like, unconstrained
         model = capi.BuiltinModel(capi.BUILTIN_TREE38, seed)
         kw = dict(eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))
@@ -47,10 +63,28 @@ def make(name, T, batch=1, fd_mode=2, seed=1, first_order_fd=None, target=None):
 def initial_trajectory(oracle, model, seed, u_sigma=0.1):
     """x0 = neutral configuration, zero velocity; u_t ~ N(0, u_sigma^2)"""
     rng = np.random.default_rng(seed)
-    x0 = np.zeros(2 * model.nv)
+    x0 = neutral_state(model)
     us = u_sigma * rng.normal(size=oracle.T * model.nv)
     xs = oracle.rollout(x0, us)
     return x0, us, xs
+
+
+def neutral_state(model):
+    """x = (neutral configuration, zero velocity); a free-flyer root starts at the unit quaternion"""
+    nq = getattr(model, "nq", model.nv)
+    x0 = np.zeros(nq + model.nv)
+    if nq != model.nv:
+        x0[6] = 1.0
+    return x0
+
+
+def random_state(model, rng, scale=1.0):
+    """a random state; the quaternion of a free-flyer root is normalised"""
+    nq = getattr(model, "nq", model.nv)
+    x = scale * rng.normal(size=nq + model.nv)
+    if nq != model.nv:
+        x[3:7] /= np.linalg.norm(x[3:7])
+    return x
 
 
 def held_trajectory(oracle, model, seed, q0_sigma=0.3, u_sigma=0.01, kp=100.0, kd=20.0):

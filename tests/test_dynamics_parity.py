@@ -11,7 +11,7 @@ which is why f_x / f_u are held to 2e-6 and the tensors are compared (a) loosely
 import numpy as np
 import pytest
 
-from problems import initial_trajectory, make
+from problems import initial_trajectory, make, random_state
 from synth import rel_err
 
 X_TOL = 1e-10
@@ -23,16 +23,16 @@ def _upload_traj(ctx, xs, us, b=0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["pendulum", "chain6", "tree38"])
+@pytest.mark.parametrize("name", ["pendulum", "chain6", "tree38", "chain6ff", "tree38ff"])
 def test_single_step_dynamics(gpu, name):
     """eval_to (problem.hpp:441-461) at random states: the from-scratch device ABA vs the oracle's, a few ulp"""
     capi = gpu
     B = 16
     model, spec, o = make(name, 1, batch=B)
     rng = np.random.default_rng(0)
-    nx, nv = 2 * model.nv, model.nv
+    nx, nv = o.nx, model.nv
     with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
-        xs = rng.normal(size=(B, 2 * nx)); us = 3.0 * rng.normal(size=(B, nv))
+        xs = np.stack([np.concatenate([random_state(model, rng), np.zeros(nx)]) for _ in range(B)]); us = 3.0 * rng.normal(size=(B, nv))
         ctx.upload("X", xs); ctx.upload("U", us)
         ctx.rollout()
         got = ctx.download("X")
@@ -43,7 +43,8 @@ def test_single_step_dynamics(gpu, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,T,sigma", [("pendulum", 50, 1.0), ("chain6", 100, 0.05), ("tree38", 20, 1.0)])
+@pytest.mark.parametrize("name,T,sigma", [("pendulum", 50, 1.0), ("chain6", 100, 0.05), ("tree38", 20, 1.0), ("chain6ff", 30, 0.05),
+                                          ("tree38ff", 20, 1.0)])
 def test_rollout_parity(gpu, name, T, sigma):
     # long open-loop rollouts of the light UR5-like wrist are chaotic for large torques: keep them gentle,
     # the arithmetic itself is pinned by test_single_step_dynamics
@@ -53,7 +54,7 @@ def test_rollout_parity(gpu, name, T, sigma):
         refs = []
         for b in range(2):
             x0, us, xs = initial_trajectory(o, model, seed=10 + b, u_sigma=sigma)
-            bad = np.full_like(xs, np.nan); bad[:2 * model.nv] = x0
+            bad = np.full_like(xs, np.nan); bad[:o.nx] = x0
             _upload_traj(ctx, bad, us, b)
             refs.append(xs)
         ctx.rollout()
@@ -80,6 +81,8 @@ def _abs_err(ctx, d, key, seq):
     ("pendulum", 50, 2), ("pendulum", 50, 1), ("pendulum", 9, 0),
     ("chain6", 10, 2), ("chain6_frame", 10, 2), ("tree38", 4, 2), ("tree38", 5, 0),
     ("tree38_frame", 4, 2), ("tree38_frame", 5, 0), ("tree38_config", 3, 2),
+    # Lie-group configurations (free-flyer root): integrate_x / difference_out on SE(3) in every stencil
+    ("chain6ff", 4, 2), ("chain6ff_frame", 5, 2), ("tree38ff", 2, 2), ("tree38ff", 3, 0), ("tree38ff_frame", 4, 2),
 ])
 def test_linearize_parity(gpu, name, T, fd_mode):
     _linearize_parity(gpu, name, T, fd_mode, 1)
@@ -146,14 +149,14 @@ def _linearize_parity(gpu, name, T, fd_mode, model_seed, ulps=8):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,T", [("pendulum", 50), ("chain6", 10), ("chain6_frame", 12), ("tree38", 12),
-                                    ("tree38_frame", 12), ("tree38_config", 6)])
+                                    ("tree38_frame", 12), ("tree38_config", 6), ("chain6ff_frame", 8), ("tree38ff_frame", 8)])
 def test_cost_seq_aug_parity(gpu, name, T):
     capi = gpu
     model, spec, o = make(name, T)
     x0, us, xs = initial_trajectory(o, model, seed=4, u_sigma=0.5)
     rng = np.random.default_rng(0)
     mults = o.alloc_affine(o.Etot)
-    mults["origin"][:] = xs[:T * o.nx] + 0.01 * rng.normal(size=T * o.nx)
+    mults["origin"][:] = _jitter_states(o, model, xs[:T * o.nx], rng)
     mults["val"][:o.Etot] = rng.normal(size=o.Etot)
     mults["jac"][:o.Etot * o.n] = rng.normal(size=o.Etot * o.n)
     ref = o.cost_seq_aug(xs, us, mults, mu=37.0)
@@ -166,6 +169,17 @@ def test_cost_seq_aug_parity(gpu, name, T):
         got = ctx.download("COSTS_OLD", 0, 1)[0]
         assert rel_err(got, ref) < 1e-11
         assert got[T] == 0.0
+
+
+def _jitter_states(o, model, xs, rng, scale=0.01):
+    """xs (+) small random tangent steps: a nearby sequence of valid states (quaternions stay unit)"""
+    nq, nv = getattr(model, "nq", model.nv), model.nv
+    out = np.array(xs, dtype=float).copy()
+    for t in range(out.size // (nq + nv)):
+        x = out[t * (nq + nv):(t + 1) * (nq + nv)]
+        x[:nq] = o.integrate(x[:nq], scale * rng.normal(size=nv))
+        x[nq:] += scale * rng.normal(size=nv)
+    return out
 
 
 def _one_iteration_inputs(o, model, seed, mu, u_sigma, jac_sigma):
@@ -190,6 +204,10 @@ def _one_iteration_inputs(o, model, seed, mu, u_sigma, jac_sigma):
     ("tree38", 10, 0, 1.0, 0.3, 0.0, 30.0),
     ("tree38_frame", 10, 0, 100.0, 0.3, 0.01, 1.0),
     ("tree38_frame", 10, 0, 100.0, 0.3, 0.01, 30.0),
+    ("chain6ff", 10, 0, 1.0, 0.05, 0.0, 1.0),           # x_new (-) x_old on SE(3) (ddp_fwd.ipp:45 with model_t::difference)
+    ("tree38ff", 10, 0, 1.0, 0.3, 0.0, 1.0),
+    ("tree38ff", 10, 0, 1.0, 0.3, 0.0, 30.0),
+    ("tree38ff_frame", 10, 0, 100.0, 0.3, 0.01, 1.0),
 ])
 def test_forward_parity(gpu, name, T, fd_mode, mu, u_sigma, jac_sigma, k_scale):
     """Same accepted step as the reference's sequential halving, same new trajectory (ddp_fwd.ipp:9-67)."""

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from problems import initial_trajectory, make
+from test_dynamics_parity import _jitter_states
 from synth import rel_err
 
 DERIV_UP = {"lfx": "LFX", "lx": "LX", "lu": "LU", "fx": "FX", "fu": "FU", "eq_val": "EQ_VAL", "eq_x": "EQ_X", "eq_u": "EQ_U"}
@@ -22,11 +23,11 @@ def _setup(capi, name, T, B, seed):
         d["lx"][:T * o.n] = 0.1 * rng.normal(size=T * o.n)
         d["lfx"][:o.n] = 0.2 * rng.normal(size=o.n)
         mults = o.alloc_affine(o.Etot)
-        mults["origin"][:] = xs[:T * o.nx] + 0.01 * rng.normal(size=T * o.nx)
+        mults["origin"][:] = _jitter_states(o, model, xs[:T * o.nx], rng)
         mults["val"][:o.Etot] = rng.normal(size=o.Etot)
         mults["jac"][:o.Etot * o.n] = 0.3 * rng.normal(size=o.Etot * o.n)
         fb = o.alloc_affine(T * o.m)
-        fb["origin"][:] = xs[:T * o.nx] + 0.01 * rng.normal(size=T * o.nx)
+        fb["origin"][:] = _jitter_states(o, model, xs[:T * o.nx], rng)
         fb["val"][:] = 0.1 * rng.normal(size=T * o.m)
         fb["jac"][:] = 0.1 * rng.normal(size=T * o.m * o.n)
         cases.append((xs, us, d, mults, fb))
@@ -50,7 +51,7 @@ def _upload(ctx, b, xs, us, d, mults, fb):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,T", [("pendulum", 50), ("chain6", 10), ("chain6_frame", 12), ("tree38_frame", 8), ("tree38_config", 4),
-                                    ("tree38", 6)])
+                                    ("tree38", 6), ("chain6ff_frame", 8), ("tree38ff_frame", 6)])
 def test_outer_loop_pieces(gpu, name, T):
     capi = gpu
     B, mu = 2, 37.0
@@ -85,7 +86,9 @@ def test_outer_loop_pieces(gpu, name, T):
                 assert rel_err(ctx.download("MULT_JAC", b, 1)[0], jac[:o.Etot * o.n]) < 1e-12
                 ctx.upload("MULT_VAL", mults["val"][:o.Etot], b, 1)          # restore for the next check
                 ctx.upload("MULT_JAC", mults["jac"][:o.Etot * o.n], b, 1)
-        # update_origin of both affine sequences at x_new = X
+        # update_origin of both affine sequences at x_new = X.  Vector-space states leave the jacobians untouched; with a
+        # free-flyer root they are multiplied by d difference(origin, .)/d finish at the old origin (mat_seq_common.hpp:77-84)
+        lie = o.nx != o.n
         ctx.update_origin(0)
         ctx.update_origin(1)
         for b, (xs, us, d, mults, fb) in enumerate(cases):
@@ -95,9 +98,16 @@ def test_outer_loop_pieces(gpu, name, T):
             assert np.array_equal(ctx.download("FB_ORIGIN", b, 1)[0], xs[:T * o.nx])
             if o.Etot:
                 assert rel_err(ctx.download("MULT_VAL", b, 1)[0], m_ref["val"][:o.Etot]) < 1e-12
-                assert np.array_equal(ctx.download("MULT_JAC", b, 1)[0], mults["jac"][:o.Etot * o.n])
+                if lie:
+                    assert rel_err(ctx.download("MULT_JAC", b, 1)[0], m_ref["jac"][:o.Etot * o.n]) < 1e-12
+                else:
+                    assert np.array_equal(ctx.download("MULT_JAC", b, 1)[0], mults["jac"][:o.Etot * o.n])
             assert rel_err(ctx.download("FB_VAL", b, 1)[0], f_ref["val"][:T * o.m]) < 1e-12
-            assert np.array_equal(ctx.download("FB_JAC", b, 1)[0], fb["jac"][:T * o.m * o.n])
+            if lie:
+                assert rel_err(ctx.download("FB_JAC", b, 1)[0], f_ref["jac"][:T * o.m * o.n]) < 1e-12
+                assert not np.array_equal(f_ref["jac"][:T * o.m * o.n], fb["jac"][:T * o.m * o.n])
+            else:
+                assert np.array_equal(ctx.download("FB_JAC", b, 1)[0], fb["jac"][:T * o.m * o.n])
 
 
 @pytest.mark.gpu
