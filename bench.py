@@ -314,6 +314,28 @@ def pmc_traffic(S):
         return None
 
 
+def usable_cores():
+    """host threads this process may really run on: the affinity mask, clipped by the cgroup CPU quota (a one-GPU share of a
+    256-thread host is 16 threads; os.cpu_count() would report the whole host)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(a, model):
     """The CPU oracle (a port of the reference algorithm; the reference itself cannot be built here) timed on this box's
     host cores on a bounded sample of the same workload: one instance, a shorter horizon (every phase is O(T): scaled
@@ -361,7 +383,7 @@ def cpu_baseline(a, model):
     t_all0 = time.perf_counter()
     ref_like = run(0, a.cpu_iterations, True)
     best = run(0, max(2, a.cpu_iterations // 2), False)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     tp0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:           # ctypes releases the GIL: one instance per thread
         list(ex.map(lambda s: run(s, 1, False), range(cores)))

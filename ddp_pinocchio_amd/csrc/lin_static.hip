@@ -293,102 +293,104 @@ __device__ __forceinline__ void offdiag_output(const LinParams& p, OutStage<NV>&
 }
 
 // ---- output stage for a row of the stencil: first direction i shared by the wave, second direction jb + lane -----
-// The NV columns such a wave owns are one contiguous block of its tensor (element (k, lane) at k + lane n), and so
-// is the block of first-order columns they read: the wave walks the block linearly, 64 consecutive doubles per
-// instruction.  The per-row quantities (f, the first-order and diagonal second-order column of direction i, x) are
-// staged in LDS once; the accelerations are left in LDS lane-major with an odd row stride (conflict free both ways).
+// The NV columns such a wave owns are one contiguous block of its tensor (element (k, lane) at k + lane n), and so is the
+// block of first-order columns they read.  The accelerations are left in LDS lane-major with an odd row stride.
 template <int NV>
 struct RowStage {
-  // rows 0 .. NV-1: the row's points; row NV: the torque-level kernel's extra point (direction i alone, see
-  // rowblock_stage); row NV+1: where the idle lanes of the wave leave their values
+  // rows 0 .. NV-1: the row's points; row NV: the torque-level kernel's extra point (direction i alone: DIAG_ROW below);
+  // row NV+1: where the idle lanes of the wave leave their values.  12.5 KB at NV = 38: twelve workgroups per CU
   double q[(NV + 2) * (NV + 1)];
-  double f0[2 * NV], a1[2 * NV], d1[2 * NV], x[2 * NV];
 };
 
-// DIAG_ROW = false: the diagonal second-order column (i, i) is read from d1.  DIAG_ROW = true (torque-level rows): lane
-// NV of the wave has evaluated the point "direction i alone" on the same cached operands (an otherwise idle lane); the
-// column (problem.hpp:192-222: 2 ((f(x + eps e_i) - f(x)) - eps f_col_i) / eps^2) is formed here, kept for the row's
-// own off-diagonal entries and written to d1 for the velocity- and configuration-level kernels that follow.
+// Lane = (column group cg = lane / 16, kk = lane % 16) owns the rows k = kk + 16 j of four columns at a time, so that what
+// depends on the row k of f alone is touched once per lane: x_k, f_k, the first-order and diagonal columns of direction i sit
+// in registers (read straight from global: 128-byte runs, the same lines for the four column groups); per element there is
+// one read of the block of first-order columns, one of the diagonal column of the second direction, at most one LDS read (the
+// acceleration, rows k >= NV) and the store(s).
+// DIAG_ROW = false: the diagonal second-order column (i, i) is read from d1g.  DIAG_ROW = true (torque-level rows): lane NV
+// of the wave has evaluated the point "direction i alone" on the same cached operands (an otherwise idle lane); the column
+// (problem.hpp:192-222: 2 ((f(x + eps e_i) - f(x)) - eps f_col_i) / eps^2) is formed here, kept for the row's own
+// off-diagonal entries and written to d1g for the velocity- and configuration-level kernels that follow.
+// out: the block [NV][n]; mirror (or null): column c at mirror + c * mstride; a2: contiguous [NV][n]; d2: column c at
+// d2 + c * dstride; i: first direction (an x index); jb: x index of the second direction of column 0, or >= 2 NV for u directions
 template <int NV, bool DIAG_ROW, class ST>
-__device__ __forceinline__ void rowblock_stage(ST& S, int lane, const double* __restrict__ f0, const double* __restrict__ a1,
-                                               double* __restrict__ d1, const double* __restrict__ xg, int i = 0, double dt = 0.0) {
-  constexpr int n = 2 * NV;
-  if constexpr (DIAG_ROW) {
-    __syncthreads();     // row NV of q is another lane's
-    const double eps = sqrt(sqrt(DBL_EPSILON));
-    const double eps2 = eps * eps;
-    for (int k = lane; k < n; k += LBS) {
-      const double f0k = f0[k], a1k = a1[k];
-      double xk = xg[k];
-      S.x[k] = xk;
-      if (k == i) xk = xk + eps;
-      double fv;
-      if (k < NV) {
-        double xv = xg[NV + k];
-        if (NV + k == i) xv = xv + eps;
-        const double vo = dt * xv;
-        fv = xk + vo;
-      } else {
-        fv = xk + S.q[NV * (NV + 1) + (k - NV)] * dt;
-      }
-      double df = fv - f0k;
-      df -= eps * a1k;
-      df *= 2;
-      const double dd = df / eps2;
-      S.f0[k] = f0k; S.a1[k] = a1k; S.d1[k] = dd;
-      d1[k] = dd;
-    }
-  } else {
-    for (int k = lane; k < n; k += LBS) { S.f0[k] = f0[k]; S.a1[k] = a1[k]; S.d1[k] = d1[k]; S.x[k] = xg[k]; }
-  }
-}
-
-// out: the block [NV][n]; mirror (or null): column c at mirror + c * mstride; a2: contiguous [NV][n]; d2: column c at d2 + c * dstride
-// i: first direction (an x index); jb: x index of the second direction of column 0, or a value >= 2 NV for u directions
-template <int NV, class ST>
-__device__ __forceinline__ void rowblock_output(const ST& S, int lane, int i, int jb, double* __restrict__ out,
-                                                double* __restrict__ mirror, int64_t mstride, const double* __restrict__ a2,
-                                                const double* __restrict__ d2, int64_t dstride, double dt) {
-  constexpr int n = 2 * NV, TOT = NV * n, UB = 8;
+__device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int jb, double* __restrict__ out, double* __restrict__ mirror,
+                                              int64_t mstride, const double* __restrict__ a2, const double* __restrict__ d2, int64_t dstride,
+                                              double dt, const double* __restrict__ f0g, const double* __restrict__ a1g,
+                                              double* __restrict__ d1g, const double* __restrict__ xg) {
+  constexpr int n = 2 * NV, RW = 16, NJ = (n + RW - 1) / RW, CG = LBS / RW, NIT = (NV + CG - 1) / CG;
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
-  for (int e0 = 0; e0 < TOT; e0 += UB * LBS) {
-    double va2[UB], vd2[UB];
+  const int kk = lane % RW, cg = lane / RW;
+  double xk[NJ], xvk[NJ], f0k[NJ], a1k[NJ], d1k[NJ];
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int e = e0 + u * LBS + lane;
-      if (e < TOT) {
-        const int c = e / n, k = e - c * n;
-        va2[u] = a2[e];
-        vd2[u] = d2[k + c * dstride];
+  for (int j = 0; j < NJ; ++j) {
+    const int k = kk + RW * j;
+    const int kc = k < n ? k : n - 1;
+    f0k[j] = f0g[kc];
+    a1k[j] = a1g[kc];
+    double x = xg[kc];
+    if (kc == i) x = x + eps;
+    xk[j] = x;
+    double xv = xg[kc < NV ? NV + kc : kc];
+    if (NV + kc == i) xv = xv + eps;
+    xvk[j] = xv;
+    if constexpr (DIAG_ROW) {
+      // problem.hpp:192-222 for direction i alone: 2 ((f(x + eps e_i) - f(x)) - eps f_col_i) / eps^2; row NV of S.q is the
+      // evaluation of that point (the wave's otherwise idle lane NV)
+      double fv;
+      if (kc < NV) {
+        const double vo = dt * xv;
+        fv = x + vo;
+      } else {
+        fv = x + S.q[NV * (NV + 1) + (kc - NV)] * dt;
       }
+      double df = fv - f0k[j];
+      df -= eps * a1k[j];
+      df *= 2;
+      const double dd = df / eps2;
+      d1k[j] = dd;
+      if (cg == 0 && k < n) d1g[k] = dd;
+    } else {
+      d1k[j] = d1g[kc];
+    }
+  }
+#pragma unroll 2
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * CG + cg;
+    const bool cv = c < NV;
+    const int cc = cv ? c : NV - 1;
+    const int jp = jb + cc;
+    double va2[NJ], vd2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int k = kk + RW * j;
+      const int kc = k < n ? k : n - 1;
+      va2[j] = a2[kc + cc * n];
+      vd2[j] = d2[kc + cc * dstride];
     }
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int e = e0 + u * LBS + lane;
-      if (e >= TOT) continue;
-      const int c = e / n, k = e - c * n;
-      const int jp = jb + c;
+    for (int j = 0; j < NJ; ++j) {
+      const int k = kk + RW * j;
+      if (!(cv && k < n)) continue;
       // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
-      double xk = S.x[k];
-      if (k == i) xk = xk + eps;
-      if (k == jp) xk = xk + eps;
+      double x = xk[j];
+      if (k == jp) x = x + eps;
       double fv;
       if (k < NV) {
-        double xv = S.x[NV + k];
-        if (NV + k == i) xv = xv + eps;
+        double xv = xvk[j];
         if (NV + k == jp) xv = xv + eps;
         const double vo = dt * xv;
-        fv = xk + vo;
+        fv = x + vo;
       } else {
-        fv = xk + S.q[c * (NV + 1) + (k - NV)] * dt;
+        fv = x + S.q[cc * (NV + 1) + (k - NV)] * dt;
       }
-      double df = fv - S.f0[k];                          // difference_out
-      df -= eps * S.a1[k];
-      df -= eps * va2[u];
+      double df = fv - f0k[j];                          // difference_out
+      df -= eps * a1k[j];
+      df -= eps * va2[j];
       df *= 2;
-      const double val = 0.5 * (df / eps2 - S.d1[k] - vd2[u]);
-      out[e] = val;
+      const double val = 0.5 * (df / eps2 - d1k[j] - vd2[j]);
+      out[k + c * n] = val;
       if (mirror) mirror[k + c * mstride] = val;
     }
   }
@@ -428,17 +430,26 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   const int iu = i - n, ju = j - n;
   // rows: the staged operands are dead once the acceleration pass is over, the output stage's buffers are not alive
   // before: one LDS region for both (the evaluation and the output stage are a barrier apart)
-  __shared__ union TauLds { double P[ROWS ? nv * PS : 1]; RowStage<nv> S; } s_lds;
+  __shared__ union TauLds { double P[ROWS ? nv * PS + nv * rbd::VC_STRIDE : 1]; RowStage<nv> S; } s_lds;
   double* s_P = s_lds.P;
-  unsigned int w = warm_block<nv * rbd::VC_STRIDE * 8>(vc, lane);
-  if constexpr (ROWS) { stage_placements<nv>(s_P, qc, lane); __syncthreads(); }
-  else w ^= warm_block<nv * rbd::QC_STRIDE * 8>(qc, lane);
+  // rows: the v-cache block of the row goes to LDS as well, in one coalesced pass (all of it in flight at once).  Through the
+  // scalar path its 76 per-joint reads are 76 serialised L2 round trips per wave (measured: 19.5 -> 17.6 ms at 64 seeds)
+  unsigned int w = 0;
+  double* s_V = s_P + nv * PS;
+  if constexpr (ROWS) {
+    for (int idx = lane; idx < nv * rbd::VC_STRIDE; idx += LBS) s_V[idx] = vc[idx];
+    stage_placements<nv>(s_P, qc, lane);
+    __syncthreads();
+  } else {
+    w = warm_block<nv * rbd::VC_STRIDE * 8>(vc, lane);
+    w ^= warm_block<nv * rbd::QC_STRIDE * 8>(qc, lane);
+  }
   if (w == 0x7fc01234u) eps = 0.0;     // never true for cache contents that are finite doubles in practice; orders the chain
   TauState<T> s;
   auto tau = [&](int k) { double v = ug[k]; if (k == iu) v = v + eps; if (k == ju) v = v + eps; return v; };
   if constexpr (ROWS) {
-    tau_up_all<T, PS>(m, s_P, vc, tau, s, std::make_integer_sequence<int, nv>{});
-    tau_down_all<T, PS>(m, s_P, vc, s, std::make_integer_sequence<int, nv>{});
+    tau_up_all<T, PS>(m, s_P, s_V, tau, s, std::make_integer_sequence<int, nv>{});
+    tau_down_all<T, PS>(m, s_P, s_V, s, std::make_integer_sequence<int, nv>{});
   } else {
     tau_up_all<T, rbd::QC_STRIDE>(m, qc, vc, tau, s, std::make_integer_sequence<int, nv>{});
     tau_down_all<T, rbd::QC_STRIDE>(m, qc, vc, s, std::make_integer_sequence<int, nv>{});
@@ -458,11 +469,11 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
 #pragma unroll
     for (int k = 0; k < nv; ++k) S.q[row * (nv + 1) + k] = s.uu[k];
     // (the staging loop comes after these stores: the evaluation must meet its first use in its own basic block)
-    rowblock_stage<nv, true>(S, lane, kp->f_val + bt * n, kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg, i, m.dt);
-    __syncthreads();
+    __syncthreads();     // row nv of q is another lane's
     // column (k, u_c) of the (x_i, u) slab of f_ux: k + c n + i n m
-    rowblock_output<nv>(S, lane, i, n, kp->fux + bt * n * mm * n + (int64_t)i * n * mm, nullptr, 0, kp->fu + bt * n * mm,
-                        kp->fuu + bt * n * mm * mm, (int64_t)n + (int64_t)n * mm, m.dt);
+    rowblock_emit<nv, true>(S, lane, i, n, kp->fux + bt * n * mm * n + (int64_t)i * n * mm, nullptr, 0, kp->fu + bt * n * mm,
+                            kp->fuu + bt * n * mm * mm, (int64_t)n + (int64_t)n * mm, m.dt, kp->f_val + bt * n,
+                            kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg);
   } else {
     __shared__ OutStage<nv> S;
 #pragma unroll
@@ -708,6 +719,8 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   // pairs: joint-major ([joint][lane]) for the generic output stage
   if constexpr (ROWS) c.uq = nullptr;
   else c.uq = &S.qdd[0][lane];
+  // (staging the articulated inertias of the row in LDS as well -- the whole 12 KB q-cache block -- was measured: 17.2 -> 16.9 ms,
+  // not worth the second code path)
   const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
   if (w == 0x7fc01234u) c.eps = 0.0;     // never true in practice; orders the evaluation behind the warm-up
   if constexpr (ROWS) { stage_placements<nv>(s_P, c.qc, lane); __syncthreads(); }
@@ -727,11 +740,11 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
     const int row = valid ? lane : nv;
 #pragma unroll
     for (int k = 0; k < nv; ++k) S.q[row * (nv + 1) + k] = s.uu[k];
-    rowblock_stage<nv, false>(S, lane, kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
     __syncthreads();
     // column (k, v_c) of slab q_i of f_xx: k + (nv + c) n + i n n; its mirror image: column q_i of slab v_c
-    rowblock_output<nv>(S, lane, i, nv, fxx + (int64_t)nv * n + (int64_t)i * n * n, fxx + (int64_t)i * n + (int64_t)nv * n * n, (int64_t)n * n,
-                        fxb + (int64_t)nv * n, fxx + (int64_t)nv * n + (int64_t)nv * n * n, (int64_t)n + (int64_t)n * n, dt);
+    rowblock_emit<nv, false>(S, lane, i, nv, fxx + (int64_t)nv * n + (int64_t)i * n * n, fxx + (int64_t)i * n + (int64_t)nv * n * n, (int64_t)n * n,
+                             fxb + (int64_t)nv * n, fxx + (int64_t)nv * n + (int64_t)nv * n * n, (int64_t)n + (int64_t)n * n, dt,
+                             kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
   } else {
     LinParams po;
     po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
