@@ -277,7 +277,7 @@ def main():
             extra["config3_single_instance"] = single_instance_leg(capi, a, model, local_rank, T)
         if extra:
             out["extra"] = extra
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and a.cpu_iterations > 0:
             out["cpu_baseline"] = cpu_baseline(a, model)
         print(json.dumps(out), flush=True)
     if shard is not None:

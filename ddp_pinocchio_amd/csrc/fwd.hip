@@ -259,6 +259,165 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
   }
 }
 
+// Second latency path: one 64-lane workgroup (= one wave) per (instance, four candidates), 16 lanes per candidate.
+// What the first one waits for at every step is global memory: the 23 KB gain matrix K_t (written by the backward sweep a whole
+// linearisation ago: an HBM read in the middle of the step), k_t, u_old, x_old, and the per-level reads of the model tables
+// inside the traversal (dependent L2 round trips, three per tree level).  Here
+//   * the model (inertias, axes, placements, level tables: rbd::CoopModel) is copied to LDS once per launch;
+//   * K_{t+1}, k_{t+1}, u_old,t+1, x_old,t+1 are requested right after the control update of step t, travel while the forward
+//     dynamics of step t run, and are parked in LDS at the end of the step (registers are the second buffer);
+//   * the workgroup is a single wave, so the exchange points of the traversal are compiler fences, not s_barrier + vmcnt(0)
+//     (rbd::coop_sync): the prefetch stays in flight through them;
+//   * the gain product is row-parallel: lane h of a candidate owns rows h, h + 16, h + 32 of K_t dx and runs down the columns
+//     in order (LDS reads, conflict-free; the four candidates read the same words).
+// Four candidates per workgroup halve the per-joint state (72 KB), which is what makes room for K_t and the model.
+template <int NJ>
+struct FwdLat2Lds {
+  static constexpr int NC = 4, NH = 16, n = 2 * NJ, nu = NJ;
+  double state[rbd::ABA_LDS_SLOTS * NJ * NC];
+  double K[nu * n];
+  double k[nu], uo[nu], xo[n];
+  double dx[NC * n], x[NC * n], u[NC * nu], qdd[NC * nu];
+  rbd::CoopModel<NJ> model;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
+  using L = FwdLat2Lds<NJ>;
+  constexpr int NC = L::NC, NH = L::NH;
+  constexpr int n = 2 * NJ, nx = 2 * NJ, nu = NJ;
+  constexpr int K2 = nu * n / 2, KR = (K2 + 63) / 64;        // K_t as 16-byte words; words per lane
+  static_assert((nu * n) % 2 == 0, "K_t is moved in 16-byte words");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  L& S = *reinterpret_cast<L*>(lds);
+  const int b = blockIdx.x / 2, half = blockIdx.x % 2;
+  if (p.state[b] != 0) return;
+  const int na = p.n_alpha;
+  if (half * NC >= na) return;
+  const int tid = threadIdx.x, al = tid / NH, h = tid % NH;
+  const int a = half * NC + al;
+  const int cand = p.round * na + a;
+  const bool live = a < na && cand <= 33;            // 2^-34 < 1e-10: never tried (ddp_fwd.ipp:35-37)
+  if (a < na && cand > 33 && h == 0) p.fw_dcost[(int64_t)b * na + a] = INFINITY;
+  const double step = ldexp(1.0, -cand);
+  const int64_t T = p.d.T;
+  const double* xo = p.x_old + (int64_t)b * (T + 1) * nx;
+  const double* uo = p.u_old + (int64_t)b * T * nu;
+  double* xw = p.fw_x + ((int64_t)b * na + (a < na ? a : 0)) * (T + 1) * nx;
+  double* uw = p.fw_u + ((int64_t)b * na + (a < na ? a : 0)) * T * nu;
+  const double* cold = p.costs_old + (int64_t)b * (T + 1);
+  const double* kg = p.fb_val + (int64_t)b * T * nu;
+  const double* Kg = p.fb_jac + (int64_t)b * T * nu * n;
+  double* dx = S.dx + al * n;
+  double* x = S.x + al * nx;
+  double* u = S.u + al * nu;
+  double* qdd = S.qdd + al * nu;
+  {
+    const DevModel& m = *p.model;
+    rbd::CoopModel<NJ>& cm = S.model;
+    for (int i = tid; i < NJ; i += 64) {
+      for (int k2 = 0; k2 < 21; ++k2) cm.I6[i][k2] = m.I6[i][k2];
+      for (int k2 = 0; k2 < 9; ++k2) cm.Rp[i][k2] = m.Rp[i][k2];
+      for (int k2 = 0; k2 < 3; ++k2) { cm.axis[i][k2] = m.axis[i][k2]; cm.pp[i][k2] = m.pp[i][k2]; }
+      cm.parent[i] = m.parent[i]; cm.jtype[i] = m.jtype[i];
+      cm.lvl_joint[i] = m.lvl_joint[i]; cm.child_list[i] = m.child_list[i];
+      cm.lvl_start[i] = m.lvl_start[i]; cm.child_start[i] = m.child_start[i];
+    }
+    if (tid == 0) {
+      cm.lvl_start[NJ] = m.lvl_start[NJ]; cm.child_start[NJ] = m.child_start[NJ];
+      cm.n_levels = m.n_levels; cm.nv = m.nv;
+      cm.gravity[0] = m.gravity[0]; cm.gravity[1] = m.gravity[1]; cm.gravity[2] = m.gravity[2];
+      cm.dt = m.dt; cm.c = m.c;
+    }
+  }
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 Kreg[KR];
+  double kreg, uoreg, xoreg0, xoreg1, coldreg;
+  auto request = [&](int64_t t) {                    // step t's operands: K_t, k_t, u_old,t, x_old,t, the old cost term
+    const d2* Kt = reinterpret_cast<const d2*>(Kg + t * nu * n);
+#pragma unroll
+    for (int j = 0; j < KR; ++j) { const int e = j * 64 + tid; Kreg[j] = Kt[e < K2 ? e : K2 - 1]; }
+    const int iu = tid < nu ? tid : nu - 1;
+    kreg = kg[t * nu + iu];
+    uoreg = uo[t * nu + iu];
+    xoreg0 = xo[t * nx + (tid < nx ? tid : nx - 1)];
+    xoreg1 = xo[t * nx + (64 + tid < nx ? 64 + tid : nx - 1)];
+    coldreg = cold[t];
+  };
+  auto park = [&]() {
+    d2* Ks = reinterpret_cast<d2*>(S.K);
+#pragma unroll
+    for (int j = 0; j < KR; ++j) { const int e = j * 64 + tid; if (e < K2) Ks[e] = Kreg[j]; }
+    if (tid < nu) { S.k[tid] = kreg; S.uo[tid] = uoreg; }
+    if (tid < nx) S.xo[tid] = xoreg0;
+    if (64 + tid < nx) S.xo[64 + tid] = xoreg1;
+  };
+  static_assert(nx <= 128, "x_old is parked by two words per lane");
+  request(0);
+  const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
+  if (live)
+    for (int i = h; i < nx; i += NH) { const double v = x0[i]; x[i] = v; xw[i] = v; }
+  park();
+  double cold_t = coldreg;
+  double dsum = 0.0;
+  const double mc = p.model->c, mdt = p.model->dt;
+  rbd::coop_sync<true>();
+  for (int64_t t = 0; t < T; ++t) {
+    if (live)
+      for (int i = h; i < n; i += NH) dx[i] = x[i] - S.xo[i];                  // :45 difference(out, old, new)
+    rbd::coop_sync<true>();
+    {
+      constexpr int NR = (nu + NH - 1) / NH;
+      double acc[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+      for (int l = 0; l < n; ++l) {
+        const double d = dx[l];
+        const double* Kc = S.K + l * nu;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int i = h + NH * r;
+          acc[r] += Kc[i < nu ? i : nu - 1] * d;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = h + NH * r;
+        if (i < nu && live) {
+          double ui = S.uo[i] + step * S.k[i];                                  // :47-48
+          ui += acc[r];                                                         // :49
+          u[i] = ui;
+          uw[t * nu + i] = ui;
+        }
+      }
+    }
+    rbd::coop_sync<true>();
+    if (h == 0 && live) {
+      double un = 0;
+      for (int i = 0; i < nu; ++i) un += u[i] * u[i];
+      const double c_new = 0.5 * mc * un;                                       // problem_t::l (no constraints on this path)
+      dsum += c_new - cold_t;
+    }
+    rbd::coop_sync<true>();                          // K_t, k_t, ... have been read: their places are free for step t + 1
+    if (t + 1 < T) request(t + 1);
+    rbd::aba_tree_coop<NJ, NC, NH, true>(S.model, x, x + NJ, u, qdd, S.state, al, h, live);   // :50
+    if (live)
+      for (int i = h; i < NJ; i += NH) {                                        // dynamics_t::eval_to, problem.hpp:441-461
+        const double vo = mdt * x[NJ + i];
+        const double qn = x[i] + vo;
+        const double vn = x[NJ + i] + qdd[i] * mdt;
+        x[i] = qn; x[NJ + i] = vn;
+        xw[(t + 1) * nx + i] = qn; xw[(t + 1) * nx + NJ + i] = vn;
+      }
+    if (t + 1 < T) { park(); cold_t = coldreg; }
+    rbd::coop_sync<true>();
+  }
+  if (h == 0 && live) {
+    dsum += 0.0 - cold[T];
+    p.fw_dcost[(int64_t)b * na + a] = dsum;
+  }
+}
+
 // accept rule (ddp_fwd.ipp:56-60): the first (= largest) candidate with sum(new - old) <= 0; the winner's
 // trajectory becomes (X_NEW, U_NEW).  grid = batch.
 __global__ void select_kernel(FwdParams p) {
@@ -349,6 +508,8 @@ int fwd_setup(ddp_hip_ctx* ctx) {
     // per device, by every context (the attribute is not process-wide)
     const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat2<38>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(FwdLat2Lds<38>)));
   }
   return DDP_HIP_OK;
 }
@@ -420,7 +581,9 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
     // tree models without constraints: the latency path (one workgroup per instance, 8 lanes per candidate)
     const bool lat_path = ctx->model_h.kind == DDP_HIP_MODEL_TREE && !ctx->model_h.ff && d.Etot == 0 && n_alpha <= 8 && d.nv == 38 &&
                           ctx->model_h.max_level_width <= 8 && getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
-    if (lat_path) {
+    if (lat_path && getenv("DDP_HIP_FWD_LAT1") == nullptr) {
+      hipLaunchKernelGGL((forward_kernel_lat2<38>), dim3((unsigned)(2 * B)), dim3(64), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+    } else if (lat_path) {
       const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));
       hipLaunchKernelGGL((forward_kernel_lat<38>), dim3((unsigned)B), dim3(64), lds, ctx->stream, p);
     } else {

@@ -40,7 +40,8 @@ __device__ __forceinline__ void mtm3(const double* A, const double* B, double* C
 }
 
 // E: rotation parent->child coordinates (row-major); r: child origin in parent coordinates
-__device__ __forceinline__ void joint_placement(const DevModel& m, int i, double q, double* E, double* r) {
+template <class M>
+__device__ __forceinline__ void joint_placement(const M& m, int i, double q, double* E, double* r) {
   const double* Rp = m.Rp[i];
   const double* a = m.axis[i];
   if (m.jtype[i] == DDP_HIP_JOINT_REVOLUTE) {
@@ -775,8 +776,38 @@ __device__ void eval_f_ucached(const DevModel& m, const double* __restrict__ qc,
 // Must be called by all lanes of the workgroup (it contains workgroup barriers); q, v, tau, qdd live in LDS.
 namespace rbd {
 
-template <int NJ, int TPB, int NH>
-__device__ void aba_tree_coop(const DevModel& m, const double* q, const double* v, const double* tau, double* qdd,
+// What the cooperative traversal reads of a model, as a plain struct a kernel can keep in LDS (fwd.hip: the per-level
+// reads of axis / I6 / parent / level tables are then LDS reads instead of dependent global loads on the critical path).
+template <int NJ>
+struct CoopModel {
+  double I6[NJ][21];
+  double axis[NJ][3];
+  double Rp[NJ][9];
+  double pp[NJ][3];
+  double gravity[3];
+  double dt, c;
+  int32_t parent[NJ], jtype[NJ];
+  int32_t lvl_start[NJ + 1], lvl_joint[NJ];
+  int32_t child_start[NJ + 1], child_list[NJ];
+  int32_t n_levels, nv;
+};
+
+// WAVE_SYNC: the workgroup is one wave -- LDS operations of a wave are processed in order, so the exchange points only have
+// to stop the compiler from moving LDS accesses across them (no s_barrier, and above all no vmcnt(0): global loads issued
+// ahead of the traversal stay in flight through it)
+template <bool WAVE_SYNC>
+__device__ __forceinline__ void coop_sync() {
+  if constexpr (WAVE_SYNC) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int NJ, int TPB, int NH, bool WAVE_SYNC = false, class M = DevModel>
+__device__ void aba_tree_coop(const M& m, const double* q, const double* v, const double* tau, double* qdd,
                               double* st, int cand, int h, bool live) {
   auto S = [&](int joint, int slot) -> double& { return st[(joint * ABA_LDS_SLOTS + slot) * TPB + cand]; };
   constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oI = 24, oU = 45, oD = 51, oT = 52, oV = 53;
@@ -791,7 +822,7 @@ __device__ void aba_tree_coop(const DevModel& m, const double* q, const double* 
 #pragma unroll
       for (int k = 0; k < 3; ++k) S(i, oR + k) = R[k];
     }
-  __syncthreads();
+  coop_sync<WAVE_SYNC>();
   for (int L = 0; L < NL; ++L) {                 // pass 1, root -> leaves
     const int idx = m.lvl_start[L] + h;
     if (live && idx < m.lvl_start[L + 1]) {
@@ -826,7 +857,7 @@ __device__ void aba_tree_coop(const DevModel& m, const double* q, const double* 
 #pragma unroll
       for (int k = 0; k < 21; ++k) S(i, oI + k) = I6[k];
     }
-    __syncthreads();
+    coop_sync<WAVE_SYNC>();
   }
   for (int L = NL - 1; L >= 0; --L) {            // pass 2, leaves -> root
     const int idx = m.lvl_start[L] + h;
@@ -847,9 +878,22 @@ __device__ void aba_tree_coop(const DevModel& m, const double* q, const double* 
         for (int k = 0; k < 6; ++k) pAi[k] += S(c, oP + k);
       }
       double d = 0, sp = 0;
+      // o is per lane: static indices under a select (dynamic ones would put IA in scratch: a store / load round trip per level)
+      const bool rev = o == 0;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) U[r] = IA[sidx(r, o)] * a[0] + IA[sidx(r, o + 1)] * a[1] + IA[sidx(r, o + 2)] * a[2];
-      for (int k = 0; k < 3; ++k) { d += a[k] * U[o + k]; sp += a[k] * pAi[o + k]; }
+      for (int r = 0; r < 6; ++r) {
+        const double i0 = rev ? IA[sidx(r, 0)] : IA[sidx(r, 3)];
+        const double i1 = rev ? IA[sidx(r, 1)] : IA[sidx(r, 4)];
+        const double i2 = rev ? IA[sidx(r, 2)] : IA[sidx(r, 5)];
+        U[r] = i0 * a[0] + i1 * a[1] + i2 * a[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double Uk = rev ? U[k] : U[3 + k];
+        const double pk = rev ? pAi[k] : pAi[3 + k];
+        d += a[k] * Uk;
+        sp += a[k] * pk;
+      }
       const double dinv = 1.0 / d;
       const double ui = tau[i] - sp;
 #pragma unroll
@@ -879,7 +923,7 @@ __device__ void aba_tree_coop(const DevModel& m, const double* q, const double* 
         for (int k = 0; k < 6; ++k) S(i, oP + k) = fp[k];
       }
     }
-    __syncthreads();
+    coop_sync<WAVE_SYNC>();
   }
   for (int L = 0; L < NL; ++L) {                 // pass 3, root -> leaves
     const int idx = m.lvl_start[L] + h;
@@ -912,7 +956,7 @@ __device__ void aba_tree_coop(const DevModel& m, const double* q, const double* 
 #pragma unroll
       for (int k = 0; k < 6; ++k) S(i, oV + k) = ap[k];
     }
-    __syncthreads();
+    coop_sync<WAVE_SYNC>();
   }
 }
 
