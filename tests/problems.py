@@ -94,13 +94,18 @@ def held_trajectory(oracle, model, seed, q0_sigma=0.3, u_sigma=0.01, kp=100.0, k
     implementation.)  Returns (x0, us, xs) with xs the oracle's rollout of us."""
     rng = np.random.default_rng(seed)
     nv, T = model.nv, oracle.T
+    nq = getattr(model, "nq", nv)
+    lie = nq != nv                     # free-flyer root: the posture error is difference(q0, q) in the tangent space
     q0 = q0_sigma * rng.normal(size=nv)
+    if lie:
+        q0 = oracle.integrate(neutral_state(model)[:nq], q0)
     x = np.concatenate([q0, np.zeros(nv)])
     x0 = x.copy()
     us = np.zeros(T * nv)
     for t in range(T):
-        q, v = x[:nv], x[nv:]
-        u = oracle.rnea(q, v, -kp * (q - q0) - kd * v) + u_sigma * rng.normal(size=nv)
+        q, v = x[:nq], x[nq:]
+        e = oracle.difference(q0, q) if lie else q - q0
+        u = oracle.rnea(q, v, -kp * e - kd * v) + u_sigma * rng.normal(size=nv)
         us[t * nv:(t + 1) * nv] = u
         x = oracle.eval_f(x, u)
     xs = oracle.rollout(x0, us)

@@ -139,6 +139,82 @@ def test_frame_constrained_chain_full_horizon(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,sweeps", [(200, False), (60, True)])
+def test_free_floating_frame_constrained(gpu, T, sweeps):
+    """BASELINE config 5 as worded: free-floating base (SE(3) root, nq = 39, nv = 38) + frame equality constraint, constrained
+    Riccati on one GPU.  x is 77 wide, the sweep's matrices 76: the case exercises nx != n everywhere.
+
+    T = 200: first-order linearisation on SE(3) (FD through integrate / difference) of all 200 steps against the oracle.
+    T = 60: the same, then the constrained backward sweep -- every step against the oracle from the device's own V(t+1) (1e-10)
+    and the whole recursion end to end -- and the line search on identical gains.
+    Why the sweep is not run at T = 200: with l = c/2 |u|^2 alone, V_xx is only positive SEMI-definite (rank 3 behind the
+    constraint at T - 2), and in double the Riccati recursion through this model's f_x lets the null directions drift:
+    lambda_min(V_xx) = -3e-12, -9e-10, -3e-8, -3e-6, -0.4 after 10, 40, 70, 90, 99 steps (measured on the oracle, both with and
+    without the free flyer), then Q_uu stops being positive definite for every reg (reg only enters Q_uu, ddp_bwd.ipp:102), and
+    the reference's restart loop never ends.  The reference runs this shape in 500-digit mpfr (test/pinocchio_spatial_eq_ddp.cpp)."""
+    capi = gpu
+    mu = 1e3
+    model, spec, o = make("tree38ff_frame", T, fd_mode=0)
+    assert o.nx == 77 and o.n == 76 and model.nq == 39
+    x0, us, xs = held_trajectory(o, model, seed=6, q0_sigma=0.2)
+    assert float(np.max(np.abs(xs))) < 10.0
+    d_ref = o.compute_derivatives(xs, us)
+    rng = np.random.default_rng(6)
+    mults = o.alloc_affine(o.Etot)
+    mults["origin"][:] = xs[:T * o.nx]
+    mults["jac"][:o.Etot * o.n] = 0.1 * rng.normal(size=o.Etot * o.n)
+    # forward-difference noise: the rounding of f over eps.  Holding 70 kg against gravity takes |u| ~ 850 through an M^-1 of
+    # ~ 170: the accelerations are differences of terms of size dt |M^-1| |u| (= max|f_u| max|u|), and that is what eps divides
+    fscale = max(1.0, float(np.max(np.abs(d_ref["f_val"]))), float(np.max(np.abs(d_ref["fu"]))) * float(np.max(np.abs(us))))
+    tol1 = 8 * EPS * fscale / E1
+    with capi.Context(spec, flags=capi.FLAG_TRACE | capi.FLAG_NO_TENSORS) as ctx:
+        _upload_traj(ctx, xs, us)
+        ctx.upload("X_NEW", xs, 0, 1); ctx.upload("U_NEW", us, 0, 1)
+        _upload_affine(ctx, "MULT", mults)
+        ctx.linearize()
+        d = o.alloc_derivs()
+        for key, seq in DERIV_SEQS.items():
+            sz = ctx.seq_size(seq)
+            if not sz:
+                continue
+            got = ctx.download(seq, 0, 1)[0]
+            d[key][:sz] = got
+            err, scale = float(np.max(np.abs(got - d_ref[key][:sz]))), max(1.0, float(np.max(np.abs(d_ref[key][:sz]))))
+            if key in ("lfx", "lx", "lu"):
+                assert err == 0.0, key
+            elif key in ("f_val", "eq_val"):
+                assert err <= 1e-12 * scale, (key, err)
+            else:
+                assert err <= tol1 * (4 if key.startswith("eq") else 1), (key, err, tol1)
+        assert o.ne[T - 2] == 3 and float(np.max(np.abs(d["eq_x"][:3 * o.n]))) > 0
+        if not sweeps:
+            return
+        ref = o.backward(d, xs, mults, 0.0, mu)
+        assert ref["restarts"] >= 0
+        rc, reg, mu_out, restarts = ctx.backward(0.0, mu)
+        assert restarts[0] == ref["restarts"] and mu_out[0] == ref["mu"] and reg[0] == ref["reg"]
+        got = {seq: ctx.download(seq, 0, 1)[0] for seq in ("FB_VAL", "FB_JAC", "VX_TRACE", "VXX_TRACE")}
+        from oracle.binding import Oracle
+        target = np.array([0.4, -0.1, 0.9])
+
+        def one_step_oracle(t):
+            e = int(o.ne[t])
+            return Oracle(model, 1, dt=0.01, c=1.0, fd_mode=0, eq_kind=capi.EQ_FRAME, eq_advance=2, ne=np.array([e], dtype=np.int64),
+                          eq_target=target[:e], frame_joint=22, frame_off=(0.0, 0.0, 0.1))
+        worst = stepwise_backward_check(one_step_oracle, o, d, xs, mults, reg[0], mu_out[0], got["VX_TRACE"], got["VXX_TRACE"],
+                                        got["FB_VAL"], got["FB_JAC"], range(T))
+        assert worst < 1e-10, worst
+        for seq, r in (("FB_VAL", ref["fb"]["val"]), ("FB_JAC", ref["fb"]["jac"]), ("VX_TRACE", ref["Vx"]), ("VXX_TRACE", ref["Vxx"])):
+            assert rel_err(got[seq], r[:got[seq].size]) < 1e-6, (seq, rel_err(got[seq], r[:got[seq].size]))
+        _upload_affine(ctx, "FB", ref["fb"])
+        step_ref, xs_ref, us_ref, _ = o.forward(xs, us, mults, ref["fb"], ref["mu"])
+        rc, step, dcost = ctx.forward(mu_out, n_alpha=8)
+        assert step[0] == step_ref, (step, step_ref)
+        assert rel_err(ctx.download("X_NEW", 0, 1)[0], xs_ref) < 1e-8
+        assert rel_err(ctx.download("U_NEW", 0, 1)[0], us_ref) < 1e-8
+
+
+@pytest.mark.gpu
 def test_talos_linearize_full_horizon_vs_oracle_across_slices(gpu):
     """The static-topology stencil at T = 200 with more (instance, t) pairs than one workspace slice (1 024) holds,
     against the ORACLE (not the generic kernels) at the pairs that straddle the slices: first / last of slice 0, first of
