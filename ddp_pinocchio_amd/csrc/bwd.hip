@@ -528,27 +528,51 @@ int enqueue_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
 // the group streams becomes graph edges, the 600 launches per group one submission.  Profiled sweeps (HIP events around
 // kernels) and DDP_HIP_BWD_NO_GRAPH=1 take the direct path.
 template <int NC, int MC>
+int build_sweep_graph(ddp_hip_ctx* ctx, const BwdParams& p0, uint64_t key_misc, ddp_hip_ctx::BwdGraph** out) {
+  ddp_hip_ctx::BwdGraph* slot = &ctx->bwd_graph[ctx->bwd_graph_next];
+  ctx->bwd_graph_next = (ctx->bwd_graph_next + 1) % 4;
+  if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
+  if (slot->graph) { (void)hipGraphDestroy(slot->graph); slot->graph = nullptr; }
+  HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = enqueue_sweep_v2<NC, MC>(ctx, p0);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (rc != DDP_HIP_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return rc != DDP_HIP_OK ? rc : DDP_HIP_E_HIP; }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(graph); return DDP_HIP_E_HIP; }
+  slot->graph = graph; slot->exec = exec; slot->key_x = p0.x; slot->key_misc = key_misc;
+  *out = slot;
+  return DDP_HIP_OK;
+}
+
+template <int NC, int MC>
 int launch_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   const uint32_t bwd_mask = (2u << DDP_HIP_K_BWD_ASSEMBLE) | (2u << DDP_HIP_K_BWD_GAINS);
+  // profiled sweeps take the direct path: events recorded by a graph's event-record nodes cannot be read back with
+  // hipEventElapsedTime on this ROCm (hipErrorInvalidHandle -- tried)
   if (!ctx->bwd_use_graph || (ctx->profile_mask & bwd_mask)) return enqueue_sweep_v2<NC, MC>(ctx, p0);
-  const void* key_x = p0.x;
   const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1);
-  ddp_hip_ctx::BwdGraph* slot = nullptr;
-  for (auto& g : ctx->bwd_graph)
-    if (g.exec && g.key_x == key_x && g.key_misc == key_misc) slot = &g;
+  auto find = [&](const void* key_x) -> ddp_hip_ctx::BwdGraph* {
+    for (auto& g : ctx->bwd_graph)
+      if (g.exec && g.key_x == key_x && g.key_misc == key_misc) return &g;
+    return nullptr;
+  };
+  ddp_hip_ctx::BwdGraph* slot = find(p0.x);
   if (!slot) {
-    slot = &ctx->bwd_graph[ctx->bwd_graph_next];
-    ctx->bwd_graph_next = (ctx->bwd_graph_next + 1) % 4;
-    if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
-    if (slot->graph) { (void)hipGraphDestroy(slot->graph); slot->graph = nullptr; }
-    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_sweep_v2<NC, MC>(ctx, p0);
-    hipGraph_t graph = nullptr;
-    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-    if (rc != DDP_HIP_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return rc != DDP_HIP_OK ? rc : DDP_HIP_E_HIP; }
-    hipGraphExec_t exec = nullptr;
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(graph); return DDP_HIP_E_HIP; }
-    slot->graph = graph; slot->exec = exec; slot->key_x = key_x; slot->key_misc = key_misc;
+    int rc = build_sweep_graph<NC, MC>(ctx, p0, key_misc, &slot);
+    if (rc != DDP_HIP_OK) return rc;
+    // the trajectory buffers trade places after every iteration (ddp_hip_swap_traj) and x is the one kernel argument that
+    // follows them: the twin graph is built now as well, so that no later sweep pays for a capture
+    const double* other = ctx->seq[DDP_HIP_SEQ_X_NEW].ptr;
+    if (other && other != p0.x && !find(other)) {
+      BwdParams p1 = p0;
+      p1.x = other;
+      ddp_hip_ctx::BwdGraph* twin = nullptr;
+      rc = build_sweep_graph<NC, MC>(ctx, p1, key_misc, &twin);
+      if (rc != DDP_HIP_OK) return rc;
+      slot = find(p0.x);
+      if (!slot) return DDP_HIP_E_HIP;
+    }
   }
   HIP_TRY(hipGraphLaunch(slot->exec, ctx->stream));
   return DDP_HIP_OK;
