@@ -274,15 +274,19 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
 template <int NJ>
 struct FwdLat2Lds {
   static constexpr int NC = 4, NH = 16, n = 2 * NJ, nu = NJ;
-  double state[rbd::ABA_LDS_SLOTS * NJ * NC];
+  double state[rbd::ABA_LDS_SLOTS2 * NJ * NC];
   double K[nu * n];
   double k[nu], uo[nu], xo[n];
   double dx[NC * n], x[NC * n], u[NC * nu], qdd[NC * nu];
   rbd::CoopModel<NJ> model;
 };
 
+#ifdef FWD_STAMPS
+__device__ unsigned long long g_fwd_stamps[12];
+#endif
+
 template <int NJ>
-__global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
+__global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   using L = FwdLat2Lds<NJ>;
   constexpr int NC = L::NC, NH = L::NH;
   constexpr int n = 2 * NJ, nx = 2 * NJ, nu = NJ;
@@ -294,11 +298,12 @@ __global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
   if (p.state[b] != 0) return;
   const int na = p.n_alpha;
   if (half * NC >= na) return;
-  const int tid = threadIdx.x, al = tid / NH, h = tid % NH;
+  // two waves: wave 0 runs the rollout, wave 1 joins it for the inertia half of the leaf -> root pass (rbd::aba_tree_coop2w)
+  const int wave = threadIdx.x / 64, tid = threadIdx.x % 64, al = tid / NH, h = tid % NH;
   const int a = half * NC + al;
   const int cand = p.round * na + a;
   const bool live = a < na && cand <= 33;            // 2^-34 < 1e-10: never tried (ddp_fwd.ipp:35-37)
-  if (a < na && cand > 33 && h == 0) p.fw_dcost[(int64_t)b * na + a] = INFINITY;
+  if (a < na && cand > 33 && h == 0 && wave == 0) p.fw_dcost[(int64_t)b * na + a] = INFINITY;
   const double step = ldexp(1.0, -cand);
   const int64_t T = p.d.T;
   const double* xo = p.x_old + (int64_t)b * (T + 1) * nx;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
   double* x = S.x + al * nx;
   double* u = S.u + al * nu;
   double* qdd = S.qdd + al * nu;
-  {
+  if (wave == 0) {
     const DevModel& m = *p.model;
     rbd::CoopModel<NJ>& cm = S.model;
     for (int i = tid; i < NJ; i += 64) {
@@ -353,15 +358,28 @@ __global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
     if (64 + tid < nx) S.xo[64 + tid] = xoreg1;
   };
   static_assert(nx <= 128, "x_old is parked by two words per lane");
-  request(0);
-  const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
-  if (live)
-    for (int i = h; i < nx; i += NH) { const double v = x0[i]; x[i] = v; xw[i] = v; }
-  park();
-  double cold_t = coldreg;
-  double dsum = 0.0;
+  double cold_t = 0.0, dsum = 0.0;
   const double mc = p.model->c, mdt = p.model->dt;
-  rbd::coop_sync<true>();
+  if (wave == 0) {
+    request(0);
+    const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
+    if (live)
+      for (int i = h; i < nx; i += NH) { const double v = x0[i]; x[i] = v; xw[i] = v; }
+    park();
+    cold_t = coldreg;
+  }
+  rbd::wg_sync_lds();                              // the model tables are in LDS for both waves
+  if (wave != 0) {
+    // the helper wave: T times the inertia half of the leaf -> root pass, in step with wave 0 through the workgroup barriers
+    for (int64_t t = 0; t < T; ++t) rbd::aba_tree_coop2w<NJ, NC, NH>(S.model, x, x + NJ, u, qdd, S.state, al, h, live, 1);
+    return;
+  }
+  rbd::FwdStamp* fs = nullptr;
+#ifdef FWD_STAMPS
+  rbd::FwdStamp fsv{};
+  fs = &fsv;
+  fsv.last = wall_clock64();
+#endif
   for (int64_t t = 0; t < T; ++t) {
     if (live)
       for (int i = h; i < n; i += NH) dx[i] = x[i] - S.xo[i];                  // :45 difference(out, old, new)
@@ -371,14 +389,16 @@ __global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
       double acc[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+      // fully unrolled: every LDS address is the lane's base plus an immediate (rolled, the loop spent 60 instructions per
+      // column on address arithmetic for 3 multiply-adds)
+      const double* Kr[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { const int i = h + NH * r; Kr[r] = S.K + (i < nu ? i : nu - 1); }
+#pragma unroll
       for (int l = 0; l < n; ++l) {
         const double d = dx[l];
-        const double* Kc = S.K + l * nu;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const int i = h + NH * r;
-          acc[r] += Kc[i < nu ? i : nu - 1] * d;
-        }
+        for (int r = 0; r < NR; ++r) acc[r] += Kr[r][l * nu] * d;
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -392,6 +412,7 @@ __global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
       }
     }
     rbd::coop_sync<true>();
+    FSTAMP(fs, 0);
     if (h == 0 && live) {
       double un = 0;
       for (int i = 0; i < nu; ++i) un += u[i] * u[i];
@@ -399,8 +420,10 @@ __global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
       dsum += c_new - cold_t;
     }
     rbd::coop_sync<true>();                          // K_t, k_t, ... have been read: their places are free for step t + 1
+    FSTAMP(fs, 1);
     if (t + 1 < T) request(t + 1);
-    rbd::aba_tree_coop<NJ, NC, NH, true>(S.model, x, x + NJ, u, qdd, S.state, al, h, live);   // :50
+    FSTAMP(fs, 2);
+    rbd::aba_tree_coop2w<NJ, NC, NH>(S.model, x, x + NJ, u, qdd, S.state, al, h, live, 0, fs);   // :50
     if (live)
       for (int i = h; i < NJ; i += NH) {                                        // dynamics_t::eval_to, problem.hpp:441-461
         const double vo = mdt * x[NJ + i];
@@ -409,9 +432,15 @@ __global__ __launch_bounds__(64) void forward_kernel_lat2(FwdParams p) {
         x[i] = qn; x[NJ + i] = vn;
         xw[(t + 1) * nx + i] = qn; xw[(t + 1) * nx + NJ + i] = vn;
       }
+    FSTAMP(fs, 7);
     if (t + 1 < T) { park(); cold_t = coldreg; }
     rbd::coop_sync<true>();
+    FSTAMP(fs, 8);
   }
+#ifdef FWD_STAMPS
+  if (tid == 0 && blockIdx.x == 0)
+    for (int i = 0; i < 12; ++i) g_fwd_stamps[i] = fsv.acc[i];
+#endif
   if (h == 0 && live) {
     dsum += 0.0 - cold[T];
     p.fw_dcost[(int64_t)b * na + a] = dsum;
@@ -523,6 +552,12 @@ void fwd_teardown(ddp_hip_ctx* ctx) {
   if (ctx->fw_state_d) (void)hipFree(ctx->fw_state_d);
 }
 
+#ifdef FWD_STAMPS
+extern "C" int ddp_hip_debug_fwd_stamps(unsigned long long* out12) {
+  return hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_fwd_stamps), sizeof(unsigned long long) * 12) == hipSuccess ? 0 : -2;
+}
+#endif
+
 extern "C" int ddp_hip_rollout(ddp_hip_ctx* ctx) {
   if (!ctx) return DDP_HIP_E_ARG;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -582,7 +617,7 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
     const bool lat_path = ctx->model_h.kind == DDP_HIP_MODEL_TREE && !ctx->model_h.ff && d.Etot == 0 && n_alpha <= 8 && d.nv == 38 &&
                           ctx->model_h.max_level_width <= 8 && getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
     if (lat_path && getenv("DDP_HIP_FWD_LAT1") == nullptr) {
-      hipLaunchKernelGGL((forward_kernel_lat2<38>), dim3((unsigned)(2 * B)), dim3(64), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+      hipLaunchKernelGGL((forward_kernel_lat2<38>), dim3((unsigned)(2 * B)), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
     } else if (lat_path) {
       const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));
       hipLaunchKernelGGL((forward_kernel_lat<38>), dim3((unsigned)B), dim3(64), lds, ctx->stream, p);

@@ -806,9 +806,20 @@ __device__ __forceinline__ void coop_sync() {
   }
 }
 
+// development (-DFWD_STAMPS, tools/fwd_stamps.py): phase clock of the forward kernel
+struct FwdStamp {
+  unsigned long long last, acc[12];
+  __device__ __forceinline__ void mark(int i) { const unsigned long long now = wall_clock64(); acc[i] += now - last; last = now; }
+};
+#ifdef FWD_STAMPS
+#define FSTAMP(fs, i) do { if (fs) (fs)->mark(i); } while (0)
+#else
+#define FSTAMP(fs, i) do { } while (0)
+#endif
+
 template <int NJ, int TPB, int NH, bool WAVE_SYNC = false, class M = DevModel>
 __device__ void aba_tree_coop(const M& m, const double* q, const double* v, const double* tau, double* qdd,
-                              double* st, int cand, int h, bool live) {
+                              double* st, int cand, int h, bool live, FwdStamp* fs = nullptr) {
   auto S = [&](int joint, int slot) -> double& { return st[(joint * ABA_LDS_SLOTS + slot) * TPB + cand]; };
   constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oI = 24, oU = 45, oD = 51, oT = 52, oV = 53;
   const int NL = m.n_levels;
@@ -823,6 +834,7 @@ __device__ void aba_tree_coop(const M& m, const double* q, const double* v, cons
       for (int k = 0; k < 3; ++k) S(i, oR + k) = R[k];
     }
   coop_sync<WAVE_SYNC>();
+  FSTAMP(fs, 3);
   for (int L = 0; L < NL; ++L) {                 // pass 1, root -> leaves
     const int idx = m.lvl_start[L] + h;
     if (live && idx < m.lvl_start[L + 1]) {
@@ -859,6 +871,7 @@ __device__ void aba_tree_coop(const M& m, const double* q, const double* v, cons
     }
     coop_sync<WAVE_SYNC>();
   }
+  FSTAMP(fs, 4);
   for (int L = NL - 1; L >= 0; --L) {            // pass 2, leaves -> root
     const int idx = m.lvl_start[L] + h;
     if (live && idx < m.lvl_start[L + 1]) {
@@ -925,6 +938,7 @@ __device__ void aba_tree_coop(const M& m, const double* q, const double* v, cons
     }
     coop_sync<WAVE_SYNC>();
   }
+  FSTAMP(fs, 5);
   for (int L = 0; L < NL; ++L) {                 // pass 3, root -> leaves
     const int idx = m.lvl_start[L] + h;
     if (live && idx < m.lvl_start[L + 1]) {
@@ -958,6 +972,192 @@ __device__ void aba_tree_coop(const M& m, const double* q, const double* v, cons
     }
     coop_sync<WAVE_SYNC>();
   }
+  FSTAMP(fs, 6);
+}
+
+// ---- two-wave variant (fwd.hip: forward_kernel_lat2) ------------------------------------------------------------------
+// A lone wave issues one FP64 instruction per 8 clocks (half of what its SIMD sustains), and the leaf -> root pass is 700 of
+// them per tree level: that pass is 54 % of a rollout step (in-kernel stamps).  Its two halves are independent once U, 1/D and
+// the articulated inertia Ia are known: the force recursion (pa, X^T pa) and the inertia contribution X^T Ia X.  Here a second
+// wave of the workgroup forms X^T Ia X while the first does the force half; both recompute the short common prefix (children's
+// sums, U, 1/D) so that neither waits for the other inside a level; one workgroup barrier per level.  The joint's own inertia
+// is read from the model table (not from a per-candidate copy), so the slots the second wave writes its contribution to (oZ) are
+// read by nobody before the level's barrier.  Every entry is formed by the same operations in the same order as in aba_tree_coop.
+constexpr int ABA_LDS_SLOTS2 = ABA_LDS_SLOTS;   // same record: the joint's own inertia now comes from the model table, its 21 slots hold the contribution
+__device__ __forceinline__ void wg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NJ, int TPB, int NH, class M>
+__device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, const double* tau, double* qdd,
+                                double* st, int cand, int h, bool live, int wave, FwdStamp* fs = nullptr) {
+  auto S = [&](int joint, int slot) -> double& { return st[(joint * ABA_LDS_SLOTS2 + slot) * TPB + cand]; };
+  constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oZ = 24, oU = 45, oD = 51, oT = 52, oV = 53;
+  const int NL = m.n_levels;
+  if (wave == 0) {
+    if (live)
+      for (int i = h; i < m.nv; i += NH) {
+        double E[9], R[3];
+        joint_placement(m, i, q[i], E, R);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S(i, oE + k) = E[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) S(i, oR + k) = R[k];
+      }
+    coop_sync<true>();
+    FSTAMP(fs, 3);
+    for (int L = 0; L < NL; ++L) {                 // pass 1, root -> leaves
+      const int idx = m.lvl_start[L] + h;
+      if (live && idx < m.lvl_start[L + 1]) {
+        const int i = m.lvl_joint[idx];
+        double E[9], R[3], vel[6], vp[6], cb[6], pA[6], Iv[6], I6[21];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+        const double* a = m.axis[i];
+        double vJ[6] = {0, 0, 0, 0, 0, 0};
+        const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+        vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+        const int par = m.parent[i];
+        if (par >= 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vp[k] = S(par, oV + k);
+          xform_motion(E, R, vp, vel);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vel[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vel[k] += vJ[k];
+        crm(vel, vJ, cb);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) I6[k] = m.I6[i][k];
+        sym6_mv(I6, vel, Iv);
+        crf(vel, Iv, pA);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { S(i, oV + k) = vel[k]; S(i, oC + k) = cb[k]; S(i, oP + k) = pA[k]; }
+      }
+      coop_sync<true>();
+    }
+    FSTAMP(fs, 4);
+  }
+  wg_sync_lds();                                   // placements (and the first wave's pass 1) are in LDS
+  for (int L = NL - 1; L >= 0; --L) {              // pass 2, leaves -> root: wave 0 the forces, wave 1 the inertias
+    const int idx = m.lvl_start[L] + h;
+    if (live && idx < m.lvl_start[L + 1]) {
+      const int i = m.lvl_joint[idx];
+      const double* a = m.axis[i];
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      const bool rev = o == 0;
+      double IA[21], U[6];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) IA[k] = m.I6[i][k];
+      const int c0 = m.child_start[i], c1 = m.child_start[i + 1];
+      for (int ci = c0; ci < c1; ++ci) {           // contributions, descending child index
+        const int c = m.child_list[ci];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) IA[k] += S(c, oZ + k);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double i0 = rev ? IA[sidx(r, 0)] : IA[sidx(r, 3)];
+        const double i1 = rev ? IA[sidx(r, 1)] : IA[sidx(r, 4)];
+        const double i2 = rev ? IA[sidx(r, 2)] : IA[sidx(r, 5)];
+        U[r] = i0 * a[0] + i1 * a[1] + i2 * a[2];
+      }
+      double d = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d += a[k] * (rev ? U[k] : U[3 + k]);
+      const double dinv = 1.0 / d;
+      const bool has_parent = m.parent[i] >= 0;
+      if (wave == 0) {
+        double pAi[6], cb[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { pAi[k] = S(i, oP + k); cb[k] = S(i, oC + k); }
+        for (int ci = c0; ci < c1; ++ci) {
+          const int c = m.child_list[ci];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) pAi[k] += S(c, oP + k);
+        }
+        double sp = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sp += a[k] * (rev ? pAi[k] : pAi[3 + k]);
+        const double ui = tau[i] - sp;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S(i, oU + k) = U[k];
+        S(i, oD) = dinv;
+        S(i, oT) = ui;
+        if (has_parent) {
+          double E[9], R[3], Ia[21], pa[6], Iac[6], fp[6];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[sidx(r, c)] - U[r] * U[c] * dinv;
+          sym6_mv(Ia, cb, Iac);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) pa[k] = pAi[k] + Iac[k] + U[k] * (ui * dinv);
+          xform_force_T(E, R, pa, fp);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) S(i, oP + k) = fp[k];
+        }
+      } else if (has_parent) {
+        double E[9], R[3], Ia[21], Z[21];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) Ia[sidx(r, c)] = IA[sidx(r, c)] - U[r] * U[c] * dinv;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) Z[k] = 0.0;
+        add_xtix(E, R, Ia, Z);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) S(i, oZ + k) = Z[k];
+      }
+    }
+    wg_sync_lds();
+  }
+  if (wave != 0) return;
+  FSTAMP(fs, 5);
+  for (int L = 0; L < NL; ++L) {                   // pass 3, root -> leaves
+    const int idx = m.lvl_start[L] + h;
+    if (live && idx < m.lvl_start[L + 1]) {
+      const int i = m.lvl_joint[idx];
+      double E[9], R[3], ap[6], accp[6], U[6], cb[6];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { U[k] = S(i, oU + k); cb[k] = S(i, oC + k); }
+      const int par = m.parent[i];
+      if (par >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) accp[k] = S(par, oV + k);
+        xform_motion(E, R, accp, ap);
+      } else {
+        const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+        xform_motion(E, R, a0, ap);
+      }
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; s += U[k] * ap[k]; }
+      const double qd = (S(i, oT) - s) * S(i, oD);
+      qdd[i] = qd;
+      const double* a = m.axis[i];
+      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      ap[o] += a[0] * qd; ap[o + 1] += a[1] * qd; ap[o + 2] += a[2] * qd;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S(i, oV + k) = ap[k];
+    }
+    coop_sync<true>();
+  }
+  FSTAMP(fs, 6);
 }
 
 }  // namespace rbd
