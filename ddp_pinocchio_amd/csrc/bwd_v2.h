@@ -218,6 +218,86 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // the round-1 kernel 99 us: both fetch-bound).  Here every elimination is a rolled loop over the pivot whose body has
 // static register indices because the running row / right-hand side is SHIFTED by one entry per step (the pivot is always
 // entry 0): r[p] <- r[p+1] - L(k+1+p, k) r_k.  Entries beyond the triangle meet zero padding of L in LDS.
+// The column loop of K4's LLT (wave 0, lane = row), in phases of six columns: inside a phase every step updates the W = M - 2 - K0
+// entries of the shifted row that are still alive at the phase's first step (a rolled loop needs one width; with the full
+// width everywhere, half of the 38 x 36 multiply-adds and operand reads worked on zero padding).
+// after a step: a[q] = entry (lane, k+1+q) updated with columns 0 .. k (a[0] is consumed into column k+1); cj[q] = L(k+1+q, k).
+template <int W, int STEPS, int M, int LP>
+__device__ __forceinline__ void chol_phase(double (&a)[M], double& lik, bool& failed, int& k, const double*& cj, int lane, int m,
+                                           double* sL, double* sLt, double& diag) {
+#pragma unroll 1
+  for (int s = 0; s < STEPS && !failed; ++s, ++k, cj += LP) {
+    double Lq[W + 1];
+#pragma unroll
+    for (int q = 1; q <= W; ++q) Lq[q] = cj[q];
+    // the critical chain: column k+1
+    const double ljk1 = readlane_f64(lik, k + 1);
+    const double a0n = a[1] - lik * ljk1;
+    const double pivn = readlane_f64(a0n, k + 1);
+    failed = !(pivn > 0.0);
+    const double dkn = sqrt(pivn);
+    const double likn = lane == k + 1 ? dkn : a0n / dkn;
+    // the rest of the row, off the critical path
+#pragma unroll
+    for (int q = 1; q <= W; ++q) a[q] = a[q + 1] - lik * Lq[q];
+    if (lane > k + 1 && lane < m) { sL[(k + 1) * LP + (lane - 2 - k)] = likn; sLt[lane * LP + (lane - 2 - k)] = likn; }
+    diag = lane == k + 1 ? dkn : diag;           // 1 / L(j, j) is formed once per lane behind the loop, not once per column
+    __builtin_amdgcn_wave_barrier();
+    lik = likn;
+  }
+}
+template <int K0, int M, int LP>
+__device__ __forceinline__ void chol_phases(double (&a)[M], double& lik, bool& failed, int& k, const double*& cj, int lane, int m,
+                                            double* sL, double* sLt, double& diag) {
+  constexpr int TOTAL = M - 1;                                     // columns 1 .. M-1 are finished by steps k = 0 .. M-2
+  constexpr int STEPS = (TOTAL - K0) >= 6 ? 6 : (TOTAL - K0);
+  constexpr int W = (M - 2 - K0) > 0 ? (M - 2 - K0) : 0;
+  chol_phase<W, STEPS, M, LP>(a, lik, failed, k, cj, lane, m, sL, sLt, diag);
+  if constexpr (K0 + STEPS < TOTAL) chol_phases<K0 + STEPS, M, LP>(a, lik, failed, k, cj, lane, m, sL, sLt, diag);
+}
+
+// One triangular substitution of K4', lane = right-hand side, the running column shifted so that the pivot is r[0] (static
+// register indices in a rolled loop).  The steps are grouped in phases of six: inside a phase every step updates W = M - 1 - K0
+// entries (those that are still alive at the phase's first step; the tail of a column of L is zero padding), the next phase
+// runs on a narrower window.  794 multiply-adds and operand reads per pass instead of 38 x 37 = 1 406.
+// DIR = +1: forward (columns of L ascending, y ascending); -1: backward (rows of L reversed, x descending).
+// La holds the operands of the current step on entry; operands of step k+1 are fetched while step k is applied.
+template <int W, int STEPS, int M, int LP, int DIR>
+__device__ __forceinline__ void subst_phase(double (&r)[M], double (&La)[M - 1], double (&Lb)[M - 1], const double*& lp, double*& outp,
+                                            const double*& dinvp) {
+  static_assert(STEPS % 2 == 0, "unrolled by two");
+#pragma unroll 1
+  for (int s = 0; s < STEPS; s += 2) {
+    {
+      const double yk = r[0] * dinvp[0];
+      outp[0] = yk;
+#pragma unroll
+      for (int q = 0; q < W; ++q) Lb[q] = lp[DIR * LP + q];
+#pragma unroll
+      for (int q = 0; q < W; ++q) r[q] = r[q + 1] - La[q] * yk;
+    }
+    {
+      const double yk = r[0] * dinvp[DIR];
+      outp[DIR] = yk;
+#pragma unroll
+      for (int q = 0; q < W; ++q) La[q] = lp[2 * DIR * LP + q];      // two columns / rows of zero padding behind the last
+#pragma unroll
+      for (int q = 0; q < W; ++q) r[q] = r[q + 1] - Lb[q] * yk;
+    }
+    lp += 2 * DIR * LP;
+    outp += 2 * DIR;
+    dinvp += 2 * DIR;
+  }
+}
+template <int K0, int M, int LP, int DIR>
+__device__ __forceinline__ void subst_phases(double (&r)[M], double (&La)[M - 1], double (&Lb)[M - 1], const double*& lp, double*& outp,
+                                             const double*& dinvp) {
+  constexpr int STEPS = (M - K0) >= 6 ? 6 : (M - K0);
+  constexpr int W = (M - 1 - K0) > 0 ? (M - 1 - K0) : 1;
+  subst_phase<W, STEPS, M, LP, DIR>(r, La, Lb, lp, outp, dinvp);
+  if constexpr (K0 + STEPS < M) subst_phases<K0 + STEPS, M, LP, DIR>(r, La, Lb, lp, outp, dinvp);
+}
+
 template <int N, int M>
 __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
   constexpr int n = N, m = M, NR = N + 1;
@@ -269,38 +349,20 @@ __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
     // 36 entries of the row are still being updated with column k from LDS.
     bool failed = false;
     double lik;                                                    // L(lane, k), the finished column k (dk on the diagonal)
+    double diag = 1.0;                                             // L(lane, lane) once column `lane` is finished
     {
       const double piv = readlane_f64(a[0], 0);
       failed = !(piv > 0.0);
       const double dk = sqrt(piv);
       lik = lane == 0 ? dk : a[0] / dk;
       if (lane > 0 && lane < m) { sL[lane - 1] = lik; sLt[lane * LP + (lane - 1)] = lik; }
-      if (lane == 0) sDinv[0] = 1.0 / dk;
+      diag = dk;                                   // lane 0's; the others take theirs in the column loop
       __builtin_amdgcn_wave_barrier();
     }
     const double* cj = static_cast<const double*>(__builtin_assume_aligned(sL, 16));
-#pragma unroll 1
-    for (int k = 0; k < M - 1 && !failed; ++k, cj += LP) {
-      // after this iteration: a[q] = entry (lane, k+1+q) updated with columns 0 .. k (a[0] is consumed into column k+1)
-      // cj[q] = L(k+1+q, k); zero beyond row M-1
-      double Lq[M - 1];
-#pragma unroll
-      for (int q = 1; q < M - 1; ++q) Lq[q] = cj[q];
-      // the critical chain: column k+1
-      const double ljk1 = readlane_f64(lik, k + 1);
-      const double a0n = a[1] - lik * ljk1;
-      const double pivn = readlane_f64(a0n, k + 1);
-      failed = !(pivn > 0.0);
-      const double dkn = sqrt(pivn);
-      const double likn = lane == k + 1 ? dkn : a0n / dkn;
-      // the rest of the row, off the critical path
-#pragma unroll
-      for (int q = 1; q < M - 1; ++q) a[q] = a[q + 1] - lik * Lq[q];
-      if (lane > k + 1 && lane < m) { sL[(k + 1) * LP + (lane - 2 - k)] = likn; sLt[lane * LP + (lane - 2 - k)] = likn; }
-      if (lane == k + 1) sDinv[k + 1] = 1.0 / dkn;
-      __builtin_amdgcn_wave_barrier();
-      lik = likn;
-    }
+    int k = 0;
+    chol_phases<0, M, LP>(a, lik, failed, k, cj, lane, m, sL, sLt, diag);
+    if (lane < m) sDinv[lane] = 1.0 / diag;        // (garbage on a failed factorisation: nobody reads it then)
     if (failed && lane == 0) s_failed = 1;
   } else if (wave == 3) {
     double* fbo = p.fb_origin + bt * nx;
@@ -337,29 +399,10 @@ __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
     {
       const double* colp = static_cast<const double*>(__builtin_assume_aligned(sL, 16));   // column k (one pointer, constant offsets)
       double* outp = out;
+      const double* dinvp = sDinv;
 #pragma unroll
       for (int q = 0; q < M - 1; ++q) La[q] = colp[q];
-#pragma unroll 1
-      for (int k = 0; k < m; k += 2) {
-        {
-          const double yk = r[0] * sDinv[k];
-          outp[0] = yk;
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) Lb[q] = colp[LP + q];
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - La[q] * yk;
-        }
-        {
-          const double yk = r[0] * sDinv[k + 1];
-          outp[1] = yk;
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) La[q] = colp[2 * LP + q];      // columns M, M+1 are zero padding
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - Lb[q] * yk;
-        }
-        colp += 2 * LP;
-        outp += 2;
-      }
+      subst_phases<0, M, LP, +1>(r, La, Lb, colp, outp, dinvp);
     }
     STAMP_T(17, 64);
     // backward: x_k = y_k / L_kk, y_i -= L_ki x_k (i < k), k descending; the column is reloaded reversed (r[q] = y_{M-1-q})
@@ -368,29 +411,10 @@ __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
     {
       const double* rowp = static_cast<const double*>(__builtin_assume_aligned(sLt + (m - 1) * LP, 16));   // row k reversed: L(k, k-1-q)
       double* outp = out + (m - 1);
+      const double* dinvp = sDinv + (m - 1);
 #pragma unroll
       for (int q = 0; q < M - 1; ++q) La[q] = rowp[q];
-#pragma unroll 1
-      for (int k = m - 1; k >= 0; k -= 2) {
-        {
-          const double xk = r[0] * sDinv[k];
-          outp[0] = xk;
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) Lb[q] = rowp[q - LP];
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - La[q] * xk;
-        }
-        {
-          const double xk = r[0] * sDinv[k - 1];
-          outp[-1] = xk;
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) La[q] = rowp[q - 2 * LP];      // rows -1, -2 are zero padding
-#pragma unroll
-          for (int q = 0; q < M - 1; ++q) r[q] = r[q + 1] - Lb[q] * xk;
-        }
-        rowp -= 2 * LP;
-        outp -= 2;
-      }
+      subst_phases<0, M, LP, -1>(r, La, Lb, rowp, outp, dinvp);
     }
     STAMP_T(18, 64);
     double* dst = rc == 0 ? p.fb_val + bt * m : p.fb_jac + bt * m * n + (rc - 1) * m;
