@@ -479,9 +479,12 @@ int enqueue_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
   size_t lds_c = sizeof(double) * (size_t)(NC + (NC + MC) * cn_max + 2 * (NC / 2 + 1) * MC);
   if (ctx->bwd_k3_lds_pad > lds_c) lds_c = ctx->bwd_k3_lds_pad;   // development: limits K3 to one workgroup per CU (room for K4' / K5 of another group)
-  const size_t lds_5 = sizeof(double) * (size_t)(NC * NC + NC * (NC + MC) + NC * CB5 + NC + d.emax);
+  const size_t lds_5 = sizeof(double) * (size_t)(NC * NC + NC * (NC + MC) + NC + d.emax);
   const unsigned nblk5 = (unsigned)((NC + MC + CB5 - 1) / CB5);
   const int G = ctx->bwd_groups;
+  // K5 (dense terms) and K3 (tensor stream) of a step both depend on K4' of the step before and on nothing else: with tensors,
+  // K5 goes to a side stream and K3 keeps its contracted blocks in a workspace of its own; K4' waits for both and forms P + C
+  const bool fork = ctx->bwd_fork && G == 1 && p0.has_tensors;
   const int64_t per = (d.batch + G - 1) / G;
   if (G > 1) {
     HIP_TRY(hipEventRecord(ctx->bwd_ev_start, ctx->stream));
@@ -493,7 +496,7 @@ int enqueue_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   for (int g = 0; g < G; ++g) {
     pg[g] = p0;
     pg[g].b0 = (int32_t)(g * per);
-    pg[g].c_accumulate = 1;
+    pg[g].c_accumulate = fork ? 2 : 1;
     const int64_t n_ = d.batch - g * per < per ? d.batch - g * per : per;
     nb[g] = n_ > 0 ? (unsigned)n_ : 0u;
     st[g] = G > 1 ? ctx->bwd_stream[g] : ctx->stream;
@@ -502,14 +505,22 @@ int enqueue_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   for (int64_t t = d.T - 1; t >= 0; --t) {
     for (int g = 0; g < G; ++g) {
       if (!nb[g]) continue;
-      prof_begin(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
-      hipLaunchKernelGGL((bwd_dense2<NC, MC>), dim3(nblk5, nb[g]), dim3(BS5), lds_5, st[g], pg[g], t);
-      prof_end(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+      if (fork) {
+        HIP_TRY(hipEventRecord(ctx->bwd_ev_fork, st[g]));
+        HIP_TRY(hipStreamWaitEvent(ctx->bwd_side, ctx->bwd_ev_fork, 0));
+        hipLaunchKernelGGL((bwd_dense2<NC, MC>), dim3(nblk5, nb[g]), dim3(BS5), lds_5, ctx->bwd_side, pg[g], t);
+        HIP_TRY(hipEventRecord(ctx->bwd_ev_join, ctx->bwd_side));
+      } else {
+        prof_begin(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+        hipLaunchKernelGGL((bwd_dense2<NC, MC>), dim3(nblk5, nb[g]), dim3(BS5), lds_5, st[g], pg[g], t);
+        prof_end(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
+      }
       if (p0.has_tensors) {
         prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
         hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, nb[g]), dim3(BSF), lds_c, st[g], pg[g], t);
         prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
       }
+      if (fork) HIP_TRY(hipStreamWaitEvent(st[g], ctx->bwd_ev_join, 0));
       prof_begin(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
       hipLaunchKernelGGL((bwd_gains2<NC, MC>), dim3(nb[g]), dim3(BS4), 0, st[g], pg[g], t);
       prof_end(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
@@ -613,7 +624,7 @@ int bwd_setup(ddp_hip_ctx* ctx) {
     const size_t lds_r = sizeof(double) * (size_t)(2 * 76 * (76 + 38));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_riccati<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense0<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-    const size_t lds_5 = sizeof(double) * (size_t)(76 * 76 + 76 * (76 + 38) + 76 * CB5 + 76 + d.emax);
+    const size_t lds_5 = sizeof(double) * (size_t)(76 * 76 + 76 * (76 + 38) + 76 + d.emax);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_dense2<76, 38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_5));
   }
   if (n == 76 && m == 38) {
@@ -629,6 +640,13 @@ int bwd_setup(ddp_hip_ctx* ctx) {
     }
     if (G > B) G = B;
     ctx->bwd_groups = (int32_t)G;
+    // DDP_HIP_BWD_FORK=1 (development): K5 on a side stream beside K3.  Measured at 64 seeds: 29.2 ms against 26.6 ms for the
+    // serial chain -- with a K5 workgroup on every CU (116 KB of LDS, a quarter of the wave slots) K3 drops from 74 to 80 us
+    // per launch and the fork / join edges cost more than the 17 us of K5 they hide.  Off by default.
+    ctx->bwd_fork = getenv("DDP_HIP_BWD_FORK") ? 1 : 0;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->bwd_side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->bwd_ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->bwd_ev_join, hipEventDisableTiming));
     if (G > 1) {
       HIP_TRY(hipEventCreateWithFlags(&ctx->bwd_ev_start, hipEventDisableTiming));
       for (int g = 0; g < G; ++g) {
@@ -652,6 +670,9 @@ void bwd_teardown(ddp_hip_ctx* ctx) {
     if (ctx->bwd_ev_done[g]) (void)hipEventDestroy(ctx->bwd_ev_done[g]);
   }
   if (ctx->bwd_ev_start) (void)hipEventDestroy(ctx->bwd_ev_start);
+  if (ctx->bwd_side) { (void)hipStreamSynchronize(ctx->bwd_side); (void)hipStreamDestroy(ctx->bwd_side); }
+  if (ctx->bwd_ev_fork) (void)hipEventDestroy(ctx->bwd_ev_fork);
+  if (ctx->bwd_ev_join) (void)hipEventDestroy(ctx->bwd_ev_join);
   if (ctx->ws_V) (void)hipFree(ctx->ws_V);
   if (ctx->ws_Q) (void)hipFree(ctx->ws_Q);
   if (ctx->ws_D) (void)hipFree(ctx->ws_D);

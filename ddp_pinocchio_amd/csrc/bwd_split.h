@@ -36,7 +36,10 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
   const int64_t bt = (int64_t)b * T + t;
 
   const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
-  double* C = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m) + n + m;
+  // c_accumulate 0: store into the Q workspace (round 1's K4 adds the rest); 1: add to what K5 left there; 2: store into a
+  // workspace of its own (K5 runs beside this kernel, K4' forms P + C)
+  double* C = p.c_accumulate == 2 ? p.ws_D + (int64_t)b * (n * n + m * n + m * m)
+                                  : p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m) + n + m;
   double* Cxx = C;
   double* Cux = Cxx + n * n;
   double* Cuu = Cux + m * n;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
     // c_accumulate: the workspace already holds every other term of Q (K5, bwd_v2.h); the tensor term comes last in the
     // reference as well (ddp_bwd.ipp:75,81,87)
     double* dst = kind == 0 ? (r < n ? Cxx + r + col * n : Cux + (r - n) + col * m) : Cuu + r + col * m;
-    *dst = p.c_accumulate ? *dst + s_out[idx] : s_out[idx];
+    *dst = p.c_accumulate == 1 ? *dst + s_out[idx] : s_out[idx];
   }
 }
 

@@ -48,8 +48,9 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* s_V = smem;                // N * N      V_xx(t+1), column-major
   double* s_F = s_V + N * N;         // N * NM     F = [f_x | f_u] of step t, column-major ld N
-  double* s_W = s_F + N * NM;        // N * CB5    W = V_xx F(:, block)
-  double* s_vx = s_W + N * CB5;      // N          V_x(t+1)
+  double* s_W = s_V;                 // N * CB5    W = V_xx F(:, block): written over V_xx once every tile of the first product has
+                                     //            left its accumulators (116 KB instead of 136: one K3 workgroup fits beside this one)
+  double* s_vx = s_F + N * NM;       // N          V_x(t+1)
   double* s_tmp = s_vx + N;          // emax       pe + mu eq   (ddp_bwd.ipp:46)
 
   const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
@@ -99,8 +100,13 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
   constexpr int KS = N / 4;
   static_assert(N % 4 == 0, "k-steps of 4");
   // W(:, block) = V_xx F(:, block): row tiles of 16 over the waves.  A(row = i, k) = V(i, k), B(k, col = c) = F(k, c0 + c)
-  constexpr int MT = (N + 15) / 16, CT = CB5 / 16;
-  for (int tile = wave; tile < MT * CT; tile += NW) {
+  constexpr int MT = (N + 15) / 16, CT = CB5 / 16, TPW1 = (MT * CT + NW - 1) / NW;
+  f64x4 wacc[TPW1];
+#pragma unroll
+  for (int it_ = 0; it_ < TPW1; ++it_) {
+    const int tile = wave + it_ * NW;
+    wacc[it_] = f64x4{0.0, 0.0, 0.0, 0.0};
+    if (tile >= MT * CT) continue;
     const int mt = tile % MT, ct = tile / MT;
     const int row = 16 * mt + l15, col = c0 + 16 * ct + l15;
     const bool rok = row < n, cok = col < NM;
@@ -113,10 +119,18 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
       const double bv = cok ? fb[4 * s] : 0.0;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
+    wacc[it_] = acc;
+  }
+  __syncthreads();                                   // every wave is done reading V_xx: W takes its place
+#pragma unroll
+  for (int it_ = 0; it_ < TPW1; ++it_) {
+    const int tile = wave + it_ * NW;
+    if (tile >= MT * CT) continue;
+    const int mt = tile % MT, ct = tile / MT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = 16 * mt + l4 + 4 * q;
-      if (r < n) s_W[r + (16 * ct + l15) * n] = acc[q];
+      if (r < n) s_W[r + (16 * ct + l15) * n] = wacc[it_][q];
     }
   }
   __syncthreads();
@@ -326,10 +340,16 @@ __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
   const double* Qxx = Q + n + m;
   const double* Qux = Qxx + n * n;
   const double* Quu = Qux + m * n;
+  // c_accumulate == 2: K3 ran beside K5 and left its contracted blocks in a workspace of its own; Q = P + C is formed here
+  // (the same single addition K3's accumulating epilogue makes: the tensor term comes last, ddp_bwd.ipp:75,81,87)
+  const bool addc = p.c_accumulate == 2 && p.has_tensors != 0;
+  const double* Cxx = p.ws_D + (int64_t)b * (n * n + m * n + m * m);
+  const double* Cux = Cxx + n * n;
+  const double* Cuu = Cux + m * n;
 
   STAMP(8);
   for (int i = tid; i < n + m; i += BS4) sQ[i] = Q[i];
-  for (int idx = tid; idx < m * n; idx += BS4) sU[idx % m + (idx / m) * LD] = Qux[idx];
+  for (int idx = tid; idx < m * n; idx += BS4) sU[idx % m + (idx / m) * LD] = addc ? Qux[idx] + Cux[idx] : Qux[idx];
   for (int i = tid; i < (M + 2) * LP; i += BS4) { sL[i] = 0.0; sLt_[i] = 0.0; }
   if (tid == 0) s_failed = 0;
   // wave 0: row `lane` of the lower triangle of Q_uu + reg I (ddp_bwd.ipp:104), entry j at a[j]
@@ -337,7 +357,11 @@ __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
   if (wave == 0) {
     const double reg = p.reg[b];
 #pragma unroll
-    for (int j = 0; j < M; ++j) a[j] = (lane < m && j <= lane) ? Quu[lane + j * m] + (lane == j ? reg : 0.0) : 0.0;
+    for (int j = 0; j < M; ++j) {
+      double qv_ = 0.0;
+      if (lane < m && j <= lane) { qv_ = Quu[lane + j * m]; if (addc) qv_ = qv_ + Cuu[lane + j * m]; qv_ = qv_ + (lane == j ? reg : 0.0); }
+      a[j] = qv_;
+    }
   }
   __syncthreads();
   STAMP(9);
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int j = 16 * jt + l4 + 4 * q;
-      qv[it_][q] = (tile < TT * TT && j < n && ib < n) ? Qxx[ib + j * n] : 0.0;
+      qv[it_][q] = (tile < TT * TT && j < n && ib < n) ? (addc ? Qxx[ib + j * n] + Cxx[ib + j * n] : Qxx[ib + j * n]) : 0.0;
     }
   }
 #pragma unroll

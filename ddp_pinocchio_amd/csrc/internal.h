@@ -95,6 +95,9 @@ struct ddp_hip_ctx {
   int32_t bwd_groups = 1;
   hipStream_t bwd_stream[8] = {};
   hipEvent_t bwd_ev_start = nullptr, bwd_ev_done[8] = {};
+  hipStream_t bwd_side = nullptr;          // K5 of a step runs here, beside K3 on the main stream (bwd.hip: enqueue_sweep_v2)
+  hipEvent_t bwd_ev_fork = nullptr, bwd_ev_join = nullptr;
+  int bwd_fork = 0;
   // the sweep as an instantiated hipGraph (600 launches per group and sweep otherwise pay the enqueue cost every time);
   // one per state of the kernel arguments (the X buffers trade places at every swap_traj)
   struct BwdGraph { const void* key_x = nullptr; uint64_t key_misc = 0; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
