@@ -198,24 +198,28 @@ __device__ __forceinline__ void tri_index(int64_t q, int Wd, int& ii, int& jj) {
   jj = (int)(q - (int64_t)a * (2 * Wd - a - 1) / 2) + a + 1;
 }
 
-// ---- output stage (problem.hpp:226-296) ---------------------------------------------------------------------------
-// Each stencil point owns one n-double column of a tensor (two for a symmetric pair) and reads four more columns
-// (its two first-order columns and its two diagonal second-order columns).  Every lane leaves the accelerations of
-// its evaluation and the six column addresses of its point in LDS; the wave then walks the points four at a time
-// with 16 lanes on each column (128-byte runs), NB such groups in flight so that their loads overlap.
+// ---- output stage of the pair kernels (problem.hpp:226-296) -----------------------------------------------------------
 template <int NV>
 struct OutStage {
-  double qdd[NV][LBS];          // [joint][lane]
+  double qdd[LBS * (NV + 1)];   // lane-major, odd row stride: (joint k, point e) at qdd[e * (NV + 1) + k] -- conflict-free for the
+                                // evaluation (lane = point) and for the output stage (16 lanes = 16 consecutive joints of one point)
   const double* in[4][LBS];     // fcol_1, fcol_2, diagonal column 1, diagonal column 2
   double* out[2][LBS];          // the point's column and its mirror image (or null)
   int pi[LBS], pj[LBS];         // the perturbed directions (rows of f see an x direction directly)
 };
 
-template <int NV, bool UNIFORM_I>
-__device__ __forceinline__ void offdiag_output(const LinParams& p, OutStage<NV>& S, bool valid, int i, int j, int64_t bt,
-                                               const double* __restrict__ xg, double dt) {
+// Each stencil point owns one n-double column of a tensor (two for a symmetric pair) and reads four more columns (its two
+// first-order columns and its two diagonal second-order columns).  Every lane leaves the accelerations of its evaluation and
+// the six column addresses of its point in LDS.  Then a 16-lane group takes one point at a time: the lanes read the point's
+// addresses once (LDS broadcasts) and own the rows k = kk + 16 j of its columns -- x_k, f_k sit in registers for the whole
+// stage, an element costs four loads, at most one (conflict-free) LDS read and the store(s); two points per group in flight.
+// (Round 1's form walked four points per 16-row chunk and re-read the addresses for every chunk: 8 LDS reads per element, the
+// acceleration among them 16-way bank-conflicted; the stage was 12.5 ms of the 86 ms linearisation.)
+template <int NV>
+__device__ __forceinline__ void offdiag_emit(const LinParams& p, OutStage<NV>& S, bool valid, int i, int j, int64_t bt,
+                                             const double* __restrict__ xg, double dt) {
   constexpr int n = 2 * NV, mm = NV;
-  constexpr int CH = 16, EPI = LBS / CH, NB = 4;
+  constexpr int RW = 16, NJ = (n + RW - 1) / RW, GRP = LBS / RW, PPG = LBS / GRP, NB = 2;
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
   const int lane = threadIdx.x;
@@ -241,50 +245,67 @@ __device__ __forceinline__ void offdiag_output(const LinParams& p, OutStage<NV>&
     S.pj[lane] = j;
   }
   __syncthreads();
-  const int kk = lane % CH, esub = lane / CH;
+  const int kk = lane % RW, grp = lane / RW;
   const double* f0 = p.f_val + bt * n;
-  for (int c0 = 0; c0 < n; c0 += CH) {
-    const int k = c0 + kk;
-    if (k >= n) continue;
-    const double f0k = f0[k];
-    const double xk = xg[k];
-    const double xvk = k < NV ? xg[NV + k] : 0.0;
-    double a1k = 0, d1k = 0;
-    if (UNIFORM_I) { a1k = S.in[0][0][k]; d1k = S.in[2][0][k]; }    // the first direction is the same for the whole wave
-    for (int r0 = 0; r0 < LBS / EPI; r0 += NB) {
-      double a1[NB], a2[NB], d1[NB], d2[NB], fv[NB];
-      double* o0[NB];
-      double* o1[NB];
+  double f0k[NJ], xk[NJ], xvk[NJ];
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int e = (r0 + u) * EPI + esub;
-        o0[u] = S.out[0][e];
-        o1[u] = S.out[1][e];
-        const int ie = S.pi[e], je = S.pj[e];
-        // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
-        double xs = k == ie ? xk + eps : xk;
-        if (k == je) xs = xs + eps;
-        if (k < NV) {
-          double xv = (NV + k) == ie ? xvk + eps : xvk;
-          if (NV + k == je) xv = xv + eps;
-          const double vo = dt * xv;
-          fv[u] = xs + vo;
-        } else {
-          fv[u] = xs + S.qdd[k - NV][e] * dt;
-        }
-        if (o0[u]) {
-          a2[u] = S.in[1][e][k]; d2[u] = S.in[3][e][k];
-          if (UNIFORM_I) { a1[u] = a1k; d1[u] = d1k; } else { a1[u] = S.in[0][e][k]; d1[u] = S.in[2][e][k]; }
+  for (int jx = 0; jx < NJ; ++jx) {
+    const int k = kk + RW * jx;
+    const int kc = k < n ? k : n - 1;
+    f0k[jx] = f0[kc];
+    xk[jx] = xg[kc];
+    xvk[jx] = kc < NV ? xg[NV + kc] : 0.0;
+  }
+  for (int pt = 0; pt < PPG; pt += NB) {
+    double a1[NB][NJ], a2[NB][NJ], d1[NB][NJ], d2[NB][NJ];
+    double* o0[NB];
+    double* o1[NB];
+    int ie[NB], je[NB], ee[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int e = (pt + u) * GRP + grp;
+      ee[u] = e;
+      o0[u] = S.out[0][e];
+      o1[u] = S.out[1][e];
+      ie[u] = S.pi[e];
+      je[u] = S.pj[e];
+      if (o0[u]) {
+        const double* q0 = S.in[0][e];
+        const double* q1 = S.in[1][e];
+        const double* q2 = S.in[2][e];
+        const double* q3 = S.in[3][e];
+#pragma unroll
+        for (int jx = 0; jx < NJ; ++jx) {
+          const int k = kk + RW * jx;
+          const int kc = k < n ? k : n - 1;
+          a1[u][jx] = q0[kc]; a2[u][jx] = q1[kc]; d1[u][jx] = q2[kc]; d2[u][jx] = q3[kc];
         }
       }
+    }
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        if (!o0[u]) continue;
-        double df = fv[u] - f0k;                          // difference_out
-        df -= eps * a1[u];
-        df -= eps * a2[u];
+    for (int u = 0; u < NB; ++u) {
+      if (!o0[u]) continue;
+#pragma unroll
+      for (int jx = 0; jx < NJ; ++jx) {
+        const int k = kk + RW * jx;
+        if (k >= n) continue;
+        // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
+        double xs = k == ie[u] ? xk[jx] + eps : xk[jx];
+        if (k == je[u]) xs = xs + eps;
+        double fv;
+        if (k < NV) {
+          double xv = (NV + k) == ie[u] ? xvk[jx] + eps : xvk[jx];
+          if (NV + k == je[u]) xv = xv + eps;
+          const double vo = dt * xv;
+          fv = xs + vo;
+        } else {
+          fv = xs + S.qdd[ee[u] * (NV + 1) + (k - NV)] * dt;
+        }
+        double df = fv - f0k[jx];                         // difference_out
+        df -= eps * a1[u][jx];
+        df -= eps * a2[u][jx];
         df *= 2;
-        const double val = 0.5 * (df / eps2 - d1[u] - d2[u]);
+        const double val = 0.5 * (df / eps2 - d1[u][jx] - d2[u][jx]);
         o0[u][k] = val;
         if (o1[u]) o1[u][k] = val;
       }
@@ -477,10 +498,10 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   } else {
     __shared__ OutStage<nv> S;
 #pragma unroll
-    for (int k = 0; k < nv; ++k) S.qdd[k][lane] = s.uu[k];
+    for (int k = 0; k < nv; ++k) S.qdd[lane * (nv + 1) + k] = s.uu[k];
     LinParams po;
     po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
-    offdiag_output<nv, false>(po, S, valid, i, j, bt, xg, m.dt);
+    offdiag_emit<nv>(po, S, valid, i, j, bt, xg, m.dt);
   }
 }
 
@@ -708,7 +729,7 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   __shared__ union VelLds { Stage S; double P[ROWS ? nv * PS : 1]; } s_lds;
   Stage& S = s_lds.S;
   double* s_P = s_lds.P;
-  VelCtx<ROWS ? 0 : LBS, ROWS ? PS : rbd::QC_STRIDE> c;
+  VelCtx<ROWS ? 0 : 1, ROWS ? PS : rbd::QC_STRIDE> c;
   c.m = p.model;
   c.qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
   c.qp = ROWS ? s_P : c.qc;
@@ -716,9 +737,9 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   c.ug = p.u + ((int64_t)b * Tn + t) * nv;
   c.i = i; c.j = j;
   c.eps = sqrt(sqrt(DBL_EPSILON));
-  // pairs: joint-major ([joint][lane]) for the generic output stage
+  // pairs: this lane's row of the output stage's acceleration buffer (lane-major, odd stride)
   if constexpr (ROWS) c.uq = nullptr;
-  else c.uq = &S.qdd[0][lane];
+  else c.uq = &S.qdd[lane * (nv + 1)];
   // (staging the articulated inertias of the row in LDS as well -- the whole 12 KB q-cache block -- was measured: 17.2 -> 16.9 ms,
   // not worth the second code path)
   const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
@@ -748,7 +769,7 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   } else {
     LinParams po;
     po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
-    offdiag_output<nv, false>(po, S, valid, i, j, bt, c.xg, dt);
+    offdiag_emit<nv>(po, S, valid, i, j, bt, c.xg, dt);
   }
 }
 
@@ -1034,14 +1055,14 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, c
   CfgState<T> s;
 #pragma unroll
   for (int e = 0; e < WS_PER_JOINT; ++e) s.w[0][e] = c.W[e * LBS];
-  CfgDownOut<LBS> o{&S.qdd[0][threadIdx.x]};
+  CfgDownOut<nv + 1> o{&S.qdd[threadIdx.x * (nv + 1)]};
   cfg_down_all<T>(c, s, o, std::make_integer_sequence<int, nv>{});
   __builtin_amdgcn_sched_barrier(0);
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   LinParams po;
   po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
-  offdiag_output<nv, false>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
+  offdiag_emit<nv>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
 }
 
 // ---- first order: forward differences of f (problem.hpp:105-126 stepping, eps = sqrt(DBL_EPSILON)) -------------------
