@@ -199,13 +199,14 @@ __device__ __forceinline__ void tri_index(int64_t q, int Wd, int& ii, int& jj) {
 }
 
 // ---- output stage of the pair kernels (problem.hpp:226-296) -----------------------------------------------------------
-template <int NV>
+// NP: points per pass of the output stage (LBS: all of the wave's at once; LBS / 2: the torque-level pair kernel, whose
+// accelerations are in registers until then, emits its two half-waves one after the other and needs half the LDS)
+template <int NV, int NP = LBS>
 struct OutStage {
-  double qdd[LBS * (NV + 1)];   // lane-major, odd row stride: (joint k, point e) at qdd[e * (NV + 1) + k] -- conflict-free for the
+  double qdd[NP * (NV + 1)];    // point-major, odd row stride: (joint k, point e) at qdd[e * (NV + 1) + k] -- conflict-free for the
                                 // evaluation (lane = point) and for the output stage (16 lanes = 16 consecutive joints of one point)
-  const double* in[4][LBS];     // fcol_1, fcol_2, diagonal column 1, diagonal column 2
-  double* out[2][LBS];          // the point's column and its mirror image (or null)
-  int pi[LBS], pj[LBS];         // the perturbed directions (rows of f see an x direction directly)
+  int pij[NP];                  // the point: first direction | second direction << 8 | valid << 16 (the six column addresses of a
+                                // point are functions of these and of wave-uniform bases: recomputed by the lanes that emit it)
 };
 
 // Each stencil point owns one n-double column of a tensor (two for a symmetric pair) and reads four more columns (its two
@@ -215,35 +216,23 @@ struct OutStage {
 // stage, an element costs four loads, at most one (conflict-free) LDS read and the store(s); two points per group in flight.
 // (Round 1's form walked four points per 16-row chunk and re-read the addresses for every chunk: 8 LDS reads per element, the
 // acceleration among them 16-way bank-conflicted; the stage was 12.5 ms of the 86 ms linearisation.)
-template <int NV>
-__device__ __forceinline__ void offdiag_emit(const LinParams& p, OutStage<NV>& S, bool valid, int i, int j, int64_t bt,
-                                             const double* __restrict__ xg, double dt) {
+// pass: which NP-block of the wave's lanes owns the slots this time (the caller has put their accelerations into S.qdd)
+template <int NV, int NP>
+__device__ __forceinline__ void offdiag_emit(const LinParams& p, OutStage<NV, NP>& S, bool valid, int i, int j, int64_t bt,
+                                             const double* __restrict__ xg, double dt, int pass = 0) {
   constexpr int n = 2 * NV, mm = NV;
-  constexpr int RW = 16, NJ = (n + RW - 1) / RW, GRP = LBS / RW, PPG = LBS / GRP, NB = 2;
+  // points in flight per group: two; one where the caller still holds the accelerations of the second half in registers
+  constexpr int RW = 16, NJ = (n + RW - 1) / RW, GRP = LBS / RW, PPG = NP / GRP, NB = NP == LBS ? 2 : 1;
+  static_assert(PPG % NB == 0, "points per group");
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
   const int lane = threadIdx.x;
-  {
-    double* fxx = p.fxx + bt * n * n * n;
-    double* fux = p.fux + bt * n * mm * n;
-    double* fuu = p.fuu + bt * n * mm * mm;
-    const double* fxb = p.fx + bt * n * n;
-    const double* fub = p.fu + bt * n * mm;
-    const bool at_x_1 = i < n, at_x_2 = j < n;
-    const int idx_1 = at_x_1 ? i : i - n, idx_2 = at_x_2 ? j : j - n;
-    S.in[0][lane] = at_x_1 ? fxb + (int64_t)idx_1 * n : fub + (int64_t)idx_1 * n;
-    S.in[1][lane] = at_x_2 ? fxb + (int64_t)idx_2 * n : fub + (int64_t)idx_2 * n;
-    S.in[2][lane] = at_x_1 ? fxx + (int64_t)idx_1 * n + (int64_t)idx_1 * n * n : fuu + (int64_t)idx_1 * n + (int64_t)idx_1 * n * mm;
-    S.in[3][lane] = at_x_2 ? fxx + (int64_t)idx_2 * n + (int64_t)idx_2 * n * n : fuu + (int64_t)idx_2 * n + (int64_t)idx_2 * n * mm;
-    double* tensor;
-    int L;
-    if (at_x_1) { if (at_x_2) { tensor = fxx; L = n; } else { tensor = fux; L = mm; } }
-    else { tensor = fuu; L = mm; }
-    S.out[0][lane] = valid ? tensor + (int64_t)idx_2 * n + (int64_t)idx_1 * n * L : nullptr;
-    S.out[1][lane] = (valid && at_x_1 == at_x_2) ? tensor + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L : nullptr;
-    S.pi[lane] = i;
-    S.pj[lane] = j;
-  }
+  if (lane / NP == pass) S.pij[lane % NP] = i | (j << 8) | ((valid ? 1 : 0) << 16);
+  double* const fxx = p.fxx + bt * n * n * n;
+  double* const fux = p.fux + bt * n * mm * n;
+  double* const fuu = p.fuu + bt * n * mm * mm;
+  const double* const fxb = p.fx + bt * n * n;
+  const double* const fub = p.fu + bt * n * mm;
   __syncthreads();
   const int kk = lane % RW, grp = lane / RW;
   const double* f0 = p.f_val + bt * n;
@@ -265,15 +254,23 @@ __device__ __forceinline__ void offdiag_emit(const LinParams& p, OutStage<NV>& S
     for (int u = 0; u < NB; ++u) {
       const int e = (pt + u) * GRP + grp;
       ee[u] = e;
-      o0[u] = S.out[0][e];
-      o1[u] = S.out[1][e];
-      ie[u] = S.pi[e];
-      je[u] = S.pj[e];
+      const int pk = S.pij[e];
+      const int i1 = pk & 255, j1 = (pk >> 8) & 255;
+      ie[u] = i1;
+      je[u] = j1;
+      const bool at_x_1 = i1 < n, at_x_2 = j1 < n;
+      const int idx_1 = at_x_1 ? i1 : i1 - n, idx_2 = at_x_2 ? j1 : j1 - n;
+      double* tensor;
+      int L;
+      if (at_x_1) { if (at_x_2) { tensor = fxx; L = n; } else { tensor = fux; L = mm; } }
+      else { tensor = fuu; L = mm; }
+      o0[u] = (pk >> 16) ? tensor + (int64_t)idx_2 * n + (int64_t)idx_1 * n * L : nullptr;
+      o1[u] = ((pk >> 16) && at_x_1 == at_x_2) ? tensor + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L : nullptr;
       if (o0[u]) {
-        const double* q0 = S.in[0][e];
-        const double* q1 = S.in[1][e];
-        const double* q2 = S.in[2][e];
-        const double* q3 = S.in[3][e];
+        const double* q0 = at_x_1 ? fxb + (int64_t)idx_1 * n : fub + (int64_t)idx_1 * n;
+        const double* q1 = at_x_2 ? fxb + (int64_t)idx_2 * n : fub + (int64_t)idx_2 * n;
+        const double* q2 = at_x_1 ? fxx + (int64_t)idx_1 * n + (int64_t)idx_1 * n * n : fuu + (int64_t)idx_1 * n + (int64_t)idx_1 * n * mm;
+        const double* q3 = at_x_2 ? fxx + (int64_t)idx_2 * n + (int64_t)idx_2 * n * n : fuu + (int64_t)idx_2 * n + (int64_t)idx_2 * n * mm;
 #pragma unroll
         for (int jx = 0; jx < NJ; ++jx) {
           const int k = kk + RW * jx;
@@ -496,12 +493,19 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
                             kp->fuu + bt * n * mm * mm, (int64_t)n + (int64_t)n * mm, m.dt, kp->f_val + bt * n,
                             kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg);
   } else {
-    __shared__ OutStage<nv> S;
-#pragma unroll
-    for (int k = 0; k < nv; ++k) S.qdd[lane * (nv + 1) + k] = s.uu[k];
+    __shared__ OutStage<nv, LBS / 2> S;
     LinParams po;
     po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
-    offdiag_emit<nv>(po, S, valid, i, j, bt, xg, m.dt);
+    const double dt = m.dt;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass) __syncthreads();                  // the first half's slots have been read
+      if (lane / (LBS / 2) == pass) {
+#pragma unroll
+        for (int k = 0; k < nv; ++k) S.qdd[(lane % (LBS / 2)) * (nv + 1) + k] = s.uu[k];
+      }
+      offdiag_emit<nv, LBS / 2>(po, S, valid, i, j, bt, xg, dt, pass);
+    }
   }
 }
 
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   } else {
     LinParams po;
     po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
-    offdiag_emit<nv>(po, S, valid, i, j, bt, c.xg, dt);
+    offdiag_emit<nv, LBS>(po, S, valid, i, j, bt, c.xg, dt);
   }
 }
 
@@ -1062,7 +1066,7 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, c
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   LinParams po;
   po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
-  offdiag_emit<nv>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
+  offdiag_emit<nv, LBS>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
 }
 
 // ---- first order: forward differences of f (problem.hpp:105-126 stepping, eps = sqrt(DBL_EPSILON)) -------------------
