@@ -232,7 +232,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // the round-1 kernel 99 us: both fetch-bound).  Here every elimination is a rolled loop over the pivot whose body has
 // static register indices because the running row / right-hand side is SHIFTED by one entry per step (the pivot is always
 // entry 0): r[p] <- r[p+1] - L(k+1+p, k) r_k.  Entries beyond the triangle meet zero padding of L in LDS.
-// The column loop of K4's LLT (wave 0, lane = row), in phases of six columns: inside a phase every step updates the W = M - 2 - K0
+constexpr int PHASE = 4;    // columns per phase of the LLT and the substitutions of K4' (even)
+
+// The column loop of K4's LLT (wave 0, lane = row), in phases of PHASE columns: inside a phase every step updates the W = M - 2 - K0
 // entries of the shifted row that are still alive at the phase's first step (a rolled loop needs one width; with the full
 // width everywhere, half of the 38 x 36 multiply-adds and operand reads worked on zero padding).
 // after a step: a[q] = entry (lane, k+1+q) updated with columns 0 .. k (a[0] is consumed into column k+1); cj[q] = L(k+1+q, k).
@@ -264,14 +266,14 @@ template <int K0, int M, int LP>
 __device__ __forceinline__ void chol_phases(double (&a)[M], double& lik, bool& failed, int& k, const double*& cj, int lane, int m,
                                             double* sL, double* sLt, double& diag) {
   constexpr int TOTAL = M - 1;                                     // columns 1 .. M-1 are finished by steps k = 0 .. M-2
-  constexpr int STEPS = (TOTAL - K0) >= 6 ? 6 : (TOTAL - K0);
+  constexpr int STEPS = (TOTAL - K0) >= PHASE ? PHASE : (TOTAL - K0);
   constexpr int W = (M - 2 - K0) > 0 ? (M - 2 - K0) : 0;
   chol_phase<W, STEPS, M, LP>(a, lik, failed, k, cj, lane, m, sL, sLt, diag);
   if constexpr (K0 + STEPS < TOTAL) chol_phases<K0 + STEPS, M, LP>(a, lik, failed, k, cj, lane, m, sL, sLt, diag);
 }
 
 // One triangular substitution of K4', lane = right-hand side, the running column shifted so that the pivot is r[0] (static
-// register indices in a rolled loop).  The steps are grouped in phases of six: inside a phase every step updates W = M - 1 - K0
+// register indices in a rolled loop).  The steps are grouped in phases of PHASE: inside a phase every step updates W = M - 1 - K0
 // entries (those that are still alive at the phase's first step; the tail of a column of L is zero padding), the next phase
 // runs on a narrower window.  794 multiply-adds and operand reads per pass instead of 38 x 37 = 1 406.
 // DIR = +1: forward (columns of L ascending, y ascending); -1: backward (rows of L reversed, x descending).
@@ -306,7 +308,7 @@ __device__ __forceinline__ void subst_phase(double (&r)[M], double (&La)[M - 1],
 template <int K0, int M, int LP, int DIR>
 __device__ __forceinline__ void subst_phases(double (&r)[M], double (&La)[M - 1], double (&Lb)[M - 1], const double*& lp, double*& outp,
                                              const double*& dinvp) {
-  constexpr int STEPS = (M - K0) >= 6 ? 6 : (M - K0);
+  constexpr int STEPS = (M - K0) >= PHASE ? PHASE : (M - K0);
   constexpr int W = (M - 1 - K0) > 0 ? (M - 1 - K0) : 1;
   subst_phase<W, STEPS, M, LP, DIR>(r, La, Lb, lp, outp, dinvp);
   if constexpr (K0 + STEPS < M) subst_phases<K0 + STEPS, M, LP, DIR>(r, La, Lb, lp, outp, dinvp);

@@ -406,8 +406,7 @@ extern "C" int ddp_hip_ctx_info(const ddp_hip_ctx* ctx, ddp_hip_info* out) {
   out->lin_path = ctx->model_h.kind == DDP_HIP_MODEL_PENDULUM ? 0 : (ctx->lin_static ? 1 + ctx->lin_static : 1);
   out->first_order = ctx->model_h.kind == DDP_HIP_MODEL_PENDULUM ? 0 : (ctx->model_h.first_order_fd ? 1 : 2);
   out->bwd_path = (d.n == 76 && d.m == 38 && getenv("DDP_HIP_GENERIC_BWD") == nullptr) ? 1 : 0;
-  out->fwd_path = (ctx->model_h.kind == DDP_HIP_MODEL_TREE && !ctx->model_h.ff && d.Etot == 0 && d.nv == 38 && ctx->model_h.max_level_width <= 8 &&
-                   getenv("DDP_HIP_FWD_SCRATCH") == nullptr) ? 1 : 0;
+  out->fwd_path = fwd_lat_supported(ctx) ? 1 : 0;
   out->has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
   int64_t bytes = 0;
   for (int s = 0; s < DDP_HIP_SEQ_COUNT; ++s)

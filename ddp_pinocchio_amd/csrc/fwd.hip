@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
 template <int NJ>
 struct FwdLat2Lds {
   static constexpr int NC = 4, NH = 16, n = 2 * NJ, nu = NJ;
-  double state[rbd::ABA_LDS_SLOTS2 * NJ * NC];
+  double state[rbd::ABA_LDS_SLOTS2 * (NJ + NJ / 8) * NC];      // (+ NJ / 8: the bank skew of rbd::aba_tree_coop2w)
   double K[nu * n];
   double k[nu], uo[nu], xo[n];
   double dx[NC * n], x[NC * n], u[NC * nu], qdd[NC * nu];
@@ -334,6 +334,19 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
       cm.gravity[0] = m.gravity[0]; cm.gravity[1] = m.gravity[1]; cm.gravity[2] = m.gravity[2];
       cm.dt = m.dt; cm.c = m.c;
     }
+    // the role words (rbd::coop_role): lane (L, hh) of the wave takes level L's hh-th joint straight from the global tables
+    for (int e = tid; e < 16 * NH; e += 64) {
+      const int L = e / NH, hh = e % NH;
+      unsigned long long r = 255;
+      if (L < m.n_levels && m.lvl_start[L] + hh < m.lvl_start[L + 1]) {
+        const int j = m.lvl_joint[m.lvl_start[L] + hh];
+        int ch[rbd::ROLE_MAX_CHILDREN] = {0, 0, 0};
+        const int nch = m.child_start[j + 1] - m.child_start[j];
+        for (int c = 0; c < nch && c < rbd::ROLE_MAX_CHILDREN; ++c) ch[c] = m.child_list[m.child_start[j] + c];
+        r = rbd::coop_role(j, m.parent[j], m.jtype[j] == DDP_HIP_JOINT_REVOLUTE, nch, ch);
+      }
+      cm.role[e] = r;
+    }
   }
   typedef double d2 __attribute__((ext_vector_type(2)));
   d2 Kreg[KR];
@@ -369,18 +382,17 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
     cold_t = coldreg;
   }
   rbd::wg_sync_lds();                              // the model tables are in LDS for both waves
-  if (wave != 0) {
-    // the helper wave: T times the inertia half of the leaf -> root pass, in step with wave 0 through the workgroup barriers
-    for (int64_t t = 0; t < T; ++t) rbd::aba_tree_coop2w<NJ, NC, NH>(S.model, x, x + NJ, u, qdd, S.state, al, h, live, 1);
-    return;
-  }
+  // one loop, one call site of the traversal for all waves (a second call site keeps the compiler from inlining it): the helper
+  // waves skip the rollout's own parts and meet wave 0 at the traversal's workgroup barriers
+  const bool lead = wave == 0;
   rbd::FwdStamp* fs = nullptr;
 #ifdef FWD_STAMPS
   rbd::FwdStamp fsv{};
-  fs = &fsv;
+  if (lead) fs = &fsv;
   fsv.last = wall_clock64();
 #endif
   for (int64_t t = 0; t < T; ++t) {
+    if (lead) {
     if (live)
       for (int i = h; i < n; i += NH) dx[i] = x[i] - S.xo[i];                  // :45 difference(out, old, new)
     rbd::coop_sync<true>();
@@ -423,7 +435,9 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
     FSTAMP(fs, 1);
     if (t + 1 < T) request(t + 1);
     FSTAMP(fs, 2);
-    rbd::aba_tree_coop2w<NJ, NC, NH>(S.model, x, x + NJ, u, qdd, S.state, al, h, live, 0, fs);   // :50
+    }
+    rbd::aba_tree_coop2w<NJ, NC, NH>(S.model, x, x + NJ, u, qdd, S.state, al, h, live, wave, fs);   // :50
+    if (!lead) continue;
     if (live)
       for (int i = h; i < NJ; i += NH) {                                        // dynamics_t::eval_to, problem.hpp:441-461
         const double vo = mdt * x[NJ + i];
@@ -438,10 +452,10 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
     FSTAMP(fs, 8);
   }
 #ifdef FWD_STAMPS
-  if (tid == 0 && blockIdx.x == 0)
+  if (threadIdx.x == 0 && blockIdx.x == 0)
     for (int i = 0; i < 12; ++i) g_fwd_stamps[i] = fsv.acc[i];
 #endif
-  if (h == 0 && live) {
+  if (h == 0 && live && lead) {
     dsum += 0.0 - cold[T];
     p.fw_dcost[(int64_t)b * na + a] = dsum;
   }
@@ -523,6 +537,17 @@ FwdParams make_params(ddp_hip_ctx* ctx) {
   } while (0)
 
 }  // namespace
+
+bool fwd_lat_supported(const ddp_hip_ctx* ctx) {
+  const DevModel& m = ctx->model_h;
+  if (m.kind != DDP_HIP_MODEL_TREE || m.ff || ctx->d.Etot != 0 || ctx->d.nv != 38 || getenv("DDP_HIP_FWD_SCRATCH") != nullptr) return false;
+  // the cooperative traversal: at most 8 joints per tree level (one helper lane each), 16 levels and 3 children per joint
+  // (rbd::coop_role packs a lane's joint of a level into one word)
+  if (m.max_level_width > 8 || m.n_levels > 16) return false;
+  for (int j = 0; j < m.nv; ++j)
+    if (m.child_start[j + 1] - m.child_start[j] > rbd::ROLE_MAX_CHILDREN) return false;
+  return true;
+}
 
 int fwd_setup(ddp_hip_ctx* ctx) {
   const Dims& d = ctx->d;
@@ -614,8 +639,7 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
     p.round = round;
     prof_begin(ctx, DDP_HIP_K_FWD_ROLLOUT);
     // tree models without constraints: the latency path (one workgroup per instance, 8 lanes per candidate)
-    const bool lat_path = ctx->model_h.kind == DDP_HIP_MODEL_TREE && !ctx->model_h.ff && d.Etot == 0 && n_alpha <= 8 && d.nv == 38 &&
-                          ctx->model_h.max_level_width <= 8 && getenv("DDP_HIP_FWD_SCRATCH") == nullptr;
+    const bool lat_path = fwd_lat_supported(ctx) && n_alpha <= 8;
     if (lat_path && getenv("DDP_HIP_FWD_LAT1") == nullptr) {
       hipLaunchKernelGGL((forward_kernel_lat2<38>), dim3((unsigned)(2 * B)), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
     } else if (lat_path) {

@@ -154,6 +154,7 @@ void prof_end(ddp_hip_ctx* ctx, int kid, hipStream_t stream = nullptr);
 int bwd_setup(ddp_hip_ctx* ctx);
 void bwd_teardown(ddp_hip_ctx* ctx);
 int fwd_setup(ddp_hip_ctx* ctx);
+bool fwd_lat_supported(const ddp_hip_ctx* ctx);   // the latency kernels of the forward sweep apply (tree, no constraints, Talos size)
 void fwd_teardown(ddp_hip_ctx* ctx);
 int lin_setup(ddp_hip_ctx* ctx);
 void lin_teardown(ddp_hip_ctx* ctx);

@@ -790,7 +790,22 @@ struct CoopModel {
   int32_t lvl_start[NJ + 1], lvl_joint[NJ];
   int32_t child_start[NJ + 1], child_list[NJ];
   int32_t n_levels, nv;
+  unsigned long long role[DDP_MAXJ > 16 * 16 ? 1 : 16 * 16];   // coop_role of (level L, helper lane h) at role[L * NH + h] (NH <= 16, <= 16 levels)
 };
+
+// a lane's joint of one tree level in one word: joint (255: none) | parent + 1 | revolute | #children | children (descending index)
+constexpr int ROLE_MAX_CHILDREN = 3;
+__host__ __device__ __forceinline__ unsigned long long coop_role(int joint, int parent, bool rev, int nch, const int* ch) {
+  unsigned long long r = (unsigned long long)(joint & 255) | ((unsigned long long)((parent + 1) & 255) << 8) | ((unsigned long long)(rev ? 1 : 0) << 16) |
+                         ((unsigned long long)(nch & 3) << 17);
+  for (int c = 0; c < nch && c < ROLE_MAX_CHILDREN; ++c) r |= (unsigned long long)(ch[c] & 255) << (19 + 8 * c);
+  return r;
+}
+__device__ __forceinline__ int role_joint(unsigned long long r) { return (int)(r & 255); }
+__device__ __forceinline__ int role_parent(unsigned long long r) { return (int)((r >> 8) & 255) - 1; }
+__device__ __forceinline__ bool role_rev(unsigned long long r) { return ((r >> 16) & 1) != 0; }
+__device__ __forceinline__ int role_nchildren(unsigned long long r) { return (int)((r >> 17) & 3); }
+__device__ __forceinline__ int role_child(unsigned long long r, int c) { return (int)((r >> (19 + 8 * c)) & 255); }
 
 // WAVE_SYNC: the workgroup is one wave -- LDS operations of a wave are processed in order, so the exchange points only have
 // to stop the compiler from moving LDS accesses across them (no s_barrier, and above all no vmcnt(0): global loads issued
@@ -987,11 +1002,14 @@ constexpr int ABA_LDS_SLOTS2 = ABA_LDS_SLOTS;   // same record: the joint's own 
 __device__ __forceinline__ void wg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NJ, int TPB, int NH, class M>
-__device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, const double* tau, double* qdd,
+__device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, const double* v, const double* tau, double* qdd,
                                 double* st, int cand, int h, bool live, int wave, FwdStamp* fs = nullptr) {
-  auto S = [&](int joint, int slot) -> double& { return st[(joint * ABA_LDS_SLOTS2 + slot) * TPB + cand]; };
+  // joints eight apart (the two arms and the head of a humanoid advance side by side) would share LDS banks: skew the records
+  auto S = [&](int joint, int slot) -> double& { return st[((joint + (joint >> 3)) * ABA_LDS_SLOTS2 + slot) * TPB + cand]; };
   constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oZ = 24, oU = 45, oD = 51, oT = 52, oV = 53;
   const int NL = m.n_levels;
+  // m.role[L * NH + h]: everything lane h needs to know about its joint of level L in one LDS word (coop_role): the level loops
+  // otherwise walk lvl_start -> lvl_joint -> parent / child_start -> child_list, four dependent LDS round trips per level and pass
   if (wave == 0) {
     if (live)
       for (int i = h; i < m.nv; i += NH) {
@@ -1005,9 +1023,9 @@ __device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, co
     coop_sync<true>();
     FSTAMP(fs, 3);
     for (int L = 0; L < NL; ++L) {                 // pass 1, root -> leaves
-      const int idx = m.lvl_start[L] + h;
-      if (live && idx < m.lvl_start[L + 1]) {
-        const int i = m.lvl_joint[idx];
+      const unsigned long long rr = m.role[L * NH + h];
+      if (live && role_joint(rr) != 255) {
+        const int i = role_joint(rr);
         double E[9], R[3], vel[6], vp[6], cb[6], pA[6], Iv[6], I6[21];
 #pragma unroll
         for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
@@ -1015,9 +1033,9 @@ __device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, co
         for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
         const double* a = m.axis[i];
         double vJ[6] = {0, 0, 0, 0, 0, 0};
-        const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+        const int o = role_rev(rr) ? 0 : 3;
         vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
-        const int par = m.parent[i];
+        const int par = role_parent(rr);
         if (par >= 0) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) vp[k] = S(par, oV + k);
@@ -1042,21 +1060,24 @@ __device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, co
   }
   wg_sync_lds();                                   // placements (and the first wave's pass 1) are in LDS
   for (int L = NL - 1; L >= 0; --L) {              // pass 2, leaves -> root: wave 0 the forces, wave 1 the inertias
-    const int idx = m.lvl_start[L] + h;
-    if (live && idx < m.lvl_start[L + 1]) {
-      const int i = m.lvl_joint[idx];
+    const unsigned long long rr = m.role[L * NH + h];
+    if (live && role_joint(rr) != 255) {
+      const int i = role_joint(rr);
       const double* a = m.axis[i];
-      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
-      const bool rev = o == 0;
+      const bool rev = role_rev(rr);
+      const int nch = role_nchildren(rr);
       double IA[21], U[6];
 #pragma unroll
       for (int k = 0; k < 21; ++k) IA[k] = m.I6[i][k];
-      const int c0 = m.child_start[i], c1 = m.child_start[i + 1];
-      for (int ci = c0; ci < c1; ++ci) {           // contributions, descending child index
-        const int c = m.child_list[ci];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) IA[k] += S(c, oZ + k);
+      for (int ci = 0; ci < ROLE_MAX_CHILDREN; ++ci) {   // contributions, descending child index
+        if (ci < nch) {
+          const int c = role_child(rr, ci);
+#pragma unroll
+          for (int k = 0; k < 21; ++k) IA[k] += S(c, oZ + k);
+        }
       }
+      FSTAMP(fs, 9);
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const double i0 = rev ? IA[sidx(r, 0)] : IA[sidx(r, 3)];
@@ -1068,15 +1089,19 @@ __device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, co
 #pragma unroll
       for (int k = 0; k < 3; ++k) d += a[k] * (rev ? U[k] : U[3 + k]);
       const double dinv = 1.0 / d;
-      const bool has_parent = m.parent[i] >= 0;
+      FSTAMP(fs, 10);
+      const bool has_parent = role_parent(rr) >= 0;
       if (wave == 0) {
         double pAi[6], cb[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) { pAi[k] = S(i, oP + k); cb[k] = S(i, oC + k); }
-        for (int ci = c0; ci < c1; ++ci) {
-          const int c = m.child_list[ci];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) pAi[k] += S(c, oP + k);
+        for (int ci = 0; ci < ROLE_MAX_CHILDREN; ++ci) {
+          if (ci < nch) {
+            const int c = role_child(rr, ci);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pAi[k] += S(c, oP + k);
+          }
         }
         double sp = 0;
 #pragma unroll
@@ -1120,14 +1145,16 @@ __device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, co
         for (int k = 0; k < 21; ++k) S(i, oZ + k) = Z[k];
       }
     }
+    FSTAMP(fs, 11);
     wg_sync_lds();
+    FSTAMP(fs, 5);
   }
   if (wave != 0) return;
   FSTAMP(fs, 5);
   for (int L = 0; L < NL; ++L) {                   // pass 3, root -> leaves
-    const int idx = m.lvl_start[L] + h;
-    if (live && idx < m.lvl_start[L + 1]) {
-      const int i = m.lvl_joint[idx];
+    const unsigned long long rr = m.role[L * NH + h];
+    if (live && role_joint(rr) != 255) {
+      const int i = role_joint(rr);
       double E[9], R[3], ap[6], accp[6], U[6], cb[6];
 #pragma unroll
       for (int k = 0; k < 9; ++k) E[k] = S(i, oE + k);
@@ -1135,7 +1162,7 @@ __device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, co
       for (int k = 0; k < 3; ++k) R[k] = S(i, oR + k);
 #pragma unroll
       for (int k = 0; k < 6; ++k) { U[k] = S(i, oU + k); cb[k] = S(i, oC + k); }
-      const int par = m.parent[i];
+      const int par = role_parent(rr);
       if (par >= 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) accp[k] = S(par, oV + k);
@@ -1150,7 +1177,7 @@ __device__ void aba_tree_coop2w(const M& m, const double* q, const double* v, co
       const double qd = (S(i, oT) - s) * S(i, oD);
       qdd[i] = qd;
       const double* a = m.axis[i];
-      const int o = m.jtype[i] == DDP_HIP_JOINT_REVOLUTE ? 0 : 3;
+      const int o = role_rev(rr) ? 0 : 3;
       ap[o] += a[0] * qd; ap[o + 1] += a[1] * qd; ap[o + 2] += a[2] * qd;
 #pragma unroll
       for (int k = 0; k < 6; ++k) S(i, oV + k) = ap[k];

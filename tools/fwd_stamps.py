@@ -20,8 +20,9 @@ for _ in range(2):
     rc, step, dcost = ctx.forward(np.full(S, 1e2), n_alpha=8)
 out = (C.c_ulonglong * 12)()
 assert capi.lib().ddp_hip_debug_fwd_stamps(out) == 0
-names = ["dx + K dx + u", "cost term", "request t+1", "placements", "pass 1", "pass 2", "pass 3", "x update", "park"]
-tot = sum(out[:9])
+names = ["dx + K dx + u", "cost term", "request t+1", "placements", "pass 1", "pass 2: wait at the level barrier", "pass 3", "x update", "park",
+         "pass 2: tables + inertia sums", "pass 2: U, D, 1/D", "pass 2: force half"]
+tot = sum(out[:12])
 for i, nme in enumerate(names):
-    print(f"{nme:16s} {out[i] / 100.0 / T:8.2f} us / step  ({100.0 * out[i] / tot:5.1f} %)")
+    print(f"{nme:36s} {out[i] / 100.0 / T:8.2f} us / step  ({100.0 * out[i] / tot:5.1f} %)")
 print(f"{'total':16s} {tot / 100.0 / T:8.2f} us / step")
