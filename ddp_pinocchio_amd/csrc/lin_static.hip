@@ -1352,7 +1352,7 @@ __device__ __forceinline__ void qv_all(const QvCtx& c, QvState<T>& s, std::integ
 }
 
 template <class T>
-__global__ __launch_bounds__(LBS) void lin_static_qvcache_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ xs,
+__global__ __launch_bounds__(LBS, 2) void lin_static_qvcache_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ xs,
                                                                  double* __restrict__ qcache, double* __restrict__ vcache) {
   constexpr int nv = T::N, n = 2 * nv, MAXCH = 8;
   const int64_t bt = blockIdx.x;
