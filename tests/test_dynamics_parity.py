@@ -236,6 +236,32 @@ def test_forward_parity(gpu, name, T, fd_mode, mu, u_sigma, jac_sigma, k_scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_alpha", [1, 3, 4, 5, 8])
+def test_forward_any_number_of_batched_steps(gpu, n_alpha):
+    """The accept decision is the sequential halving's whatever the number of step sizes rolled out together (ddp_fwd.ipp:29-64):
+    rounds of n_alpha candidates.  On the latency kernel this also exercises workgroups with no live candidate (n_alpha <= 4:
+    the second workgroup of an instance leaves at once) and partly filled ones."""
+    capi = gpu
+    T = 10
+    model, spec, o = make("tree38", T, fd_mode=0)
+    xs, us, d, mults, bw = _one_iteration_inputs(o, model, 21, 1.0, 0.3, 0.0)
+    bw["fb"]["val"] *= 30.0                                      # overshooting feed-forward: several halvings
+    step_ref, xs_ref, us_ref, n_evals = o.forward(xs, us, mults, bw["fb"], bw["mu"])
+    assert n_evals > 1
+    with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
+        assert ctx.info()["fwd_path"] == 1
+        _upload_traj(ctx, xs, us)
+        ctx.upload("X_NEW", xs, 0, 1)
+        ctx.upload("U_NEW", us, 0, 1)
+        for k, s_ in (("origin", "FB_ORIGIN"), ("val", "FB_VAL"), ("jac", "FB_JAC")):
+            ctx.upload(s_, bw["fb"][k][:ctx.seq_size(s_)], 0, 1)
+        rc, step, dcost = ctx.forward(bw["mu"], n_alpha=n_alpha)
+        assert step[0] == step_ref, (n_alpha, step, step_ref)
+        assert rel_err(ctx.download("X_NEW", 0, 1)[0], xs_ref) < 1e-9
+        assert rel_err(ctx.download("U_NEW", 0, 1)[0], us_ref) < 1e-9
+
+
+@pytest.mark.gpu
 def test_forward_line_search_floor(gpu):
     """A feedback that can only increase the cost: every candidate down to 2^-33 is rejected, the call reports
     the floor, returns step = 2^-34 and leaves the last tried rollout in X_NEW (ddp_fwd.ipp:35-37,59)."""
