@@ -285,7 +285,8 @@ struct FwdLat2Lds {
 __device__ unsigned long long g_fwd_stamps[12];
 #endif
 
-template <int NJ>
+// OPEN: the open-loop rollout of make_trajectory (ddp.hpp:392-415) on the same machinery: one candidate, u = U as given, x to X
+template <int NJ, bool OPEN = false>
 __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   using L = FwdLat2Lds<NJ>;
   constexpr int NC = L::NC, NH = L::NH;
@@ -294,22 +295,22 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   static_assert((nu * n) % 2 == 0, "K_t is moved in 16-byte words");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   L& S = *reinterpret_cast<L*>(lds);
-  const int b = blockIdx.x / 2, half = blockIdx.x % 2;
-  if (p.state[b] != 0) return;
-  const int na = p.n_alpha;
+  const int b = OPEN ? blockIdx.x : blockIdx.x / 2, half = OPEN ? 0 : blockIdx.x % 2;
+  if (!OPEN && p.state[b] != 0) return;
+  const int na = OPEN ? 1 : p.n_alpha;
   if (half * NC >= na) return;
   // two waves: wave 0 runs the rollout, wave 1 joins it for the inertia half of the leaf -> root pass (rbd::aba_tree_coop2w)
   const int wave = threadIdx.x / 64, tid = threadIdx.x % 64, al = tid / NH, h = tid % NH;
   const int a = half * NC + al;
   const int cand = p.round * na + a;
   const bool live = a < na && cand <= 33;            // 2^-34 < 1e-10: never tried (ddp_fwd.ipp:35-37)
-  if (a < na && cand > 33 && h == 0 && wave == 0) p.fw_dcost[(int64_t)b * na + a] = INFINITY;
+  if (!OPEN && a < na && cand > 33 && h == 0 && wave == 0) p.fw_dcost[(int64_t)b * na + a] = INFINITY;
   const double step = ldexp(1.0, -cand);
   const int64_t T = p.d.T;
   const double* xo = p.x_old + (int64_t)b * (T + 1) * nx;
   const double* uo = p.u_old + (int64_t)b * T * nu;
-  double* xw = p.fw_x + ((int64_t)b * na + (a < na ? a : 0)) * (T + 1) * nx;
-  double* uw = p.fw_u + ((int64_t)b * na + (a < na ? a : 0)) * T * nu;
+  double* xw = OPEN ? const_cast<double*>(p.x_old) + (int64_t)b * (T + 1) * nx : p.fw_x + ((int64_t)b * na + (a < na ? a : 0)) * (T + 1) * nx;
+  double* uw = OPEN ? nullptr : p.fw_u + ((int64_t)b * na + (a < na ? a : 0)) * T * nu;
   const double* cold = p.costs_old + (int64_t)b * (T + 1);
   const double* kg = p.fb_val + (int64_t)b * T * nu;
   const double* Kg = p.fb_jac + (int64_t)b * T * nu * n;
@@ -350,34 +351,39 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   }
   typedef double d2 __attribute__((ext_vector_type(2)));
   d2 Kreg[KR];
-  double kreg, uoreg, xoreg0, xoreg1, coldreg;
+  double kreg = 0.0, uoreg = 0.0, xoreg0 = 0.0, xoreg1 = 0.0, coldreg = 0.0;
   auto request = [&](int64_t t) {                    // step t's operands: K_t, k_t, u_old,t, x_old,t, the old cost term
-    const d2* Kt = reinterpret_cast<const d2*>(Kg + t * nu * n);
-#pragma unroll
-    for (int j = 0; j < KR; ++j) { const int e = j * 64 + tid; Kreg[j] = Kt[e < K2 ? e : K2 - 1]; }
     const int iu = tid < nu ? tid : nu - 1;
-    kreg = kg[t * nu + iu];
     uoreg = uo[t * nu + iu];
-    xoreg0 = xo[t * nx + (tid < nx ? tid : nx - 1)];
-    xoreg1 = xo[t * nx + (64 + tid < nx ? 64 + tid : nx - 1)];
-    coldreg = cold[t];
+    if constexpr (!OPEN) {
+      const d2* Kt = reinterpret_cast<const d2*>(Kg + t * nu * n);
+#pragma unroll
+      for (int j = 0; j < KR; ++j) { const int e = j * 64 + tid; Kreg[j] = Kt[e < K2 ? e : K2 - 1]; }
+      kreg = kg[t * nu + iu];
+      xoreg0 = xo[t * nx + (tid < nx ? tid : nx - 1)];
+      xoreg1 = xo[t * nx + (64 + tid < nx ? 64 + tid : nx - 1)];
+      coldreg = cold[t];
+    }
   };
   auto park = [&]() {
-    d2* Ks = reinterpret_cast<d2*>(S.K);
+    if (tid < nu) S.uo[tid] = uoreg;
+    if constexpr (!OPEN) {
+      d2* Ks = reinterpret_cast<d2*>(S.K);
 #pragma unroll
-    for (int j = 0; j < KR; ++j) { const int e = j * 64 + tid; if (e < K2) Ks[e] = Kreg[j]; }
-    if (tid < nu) { S.k[tid] = kreg; S.uo[tid] = uoreg; }
-    if (tid < nx) S.xo[tid] = xoreg0;
-    if (64 + tid < nx) S.xo[64 + tid] = xoreg1;
+      for (int j = 0; j < KR; ++j) { const int e = j * 64 + tid; if (e < K2) Ks[e] = Kreg[j]; }
+      if (tid < nu) S.k[tid] = kreg;
+      if (tid < nx) S.xo[tid] = xoreg0;
+      if (64 + tid < nx) S.xo[64 + tid] = xoreg1;
+    }
   };
   static_assert(nx <= 128, "x_old is parked by two words per lane");
   double cold_t = 0.0, dsum = 0.0;
   const double mc = p.model->c, mdt = p.model->dt;
   if (wave == 0) {
     request(0);
-    const double* x0 = p.x_new + (int64_t)b * (T + 1) * nx;        // x_new,0 is preset by the caller (ddp.hpp:752)
+    const double* x0 = OPEN ? xw : p.x_new + (int64_t)b * (T + 1) * nx;   // x_new,0 is preset by the caller (ddp.hpp:752)
     if (live)
-      for (int i = h; i < nx; i += NH) { const double v = x0[i]; x[i] = v; xw[i] = v; }
+      for (int i = h; i < nx; i += NH) { const double v = x0[i]; x[i] = v; if (!OPEN) xw[i] = v; }
     park();
     cold_t = coldreg;
   }
@@ -393,6 +399,10 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
 #endif
   for (int64_t t = 0; t < T; ++t) {
     if (lead) {
+    if constexpr (OPEN) {
+      if (live)
+        for (int i = h; i < nu; i += NH) u[i] = S.uo[i];
+    } else {
     if (live)
       for (int i = h; i < n; i += NH) dx[i] = x[i] - S.xo[i];                  // :45 difference(out, old, new)
     rbd::coop_sync<true>();
@@ -431,6 +441,7 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
       const double c_new = 0.5 * mc * un;                                       // problem_t::l (no constraints on this path)
       dsum += c_new - cold_t;
     }
+    }
     rbd::coop_sync<true>();                          // K_t, k_t, ... have been read: their places are free for step t + 1
     FSTAMP(fs, 1);
     if (t + 1 < T) request(t + 1);
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   if (threadIdx.x == 0 && blockIdx.x == 0)
     for (int i = 0; i < 12; ++i) g_fwd_stamps[i] = fsv.acc[i];
 #endif
-  if (h == 0 && live && lead) {
+  if (!OPEN && h == 0 && live && lead) {
     dsum += 0.0 - cold[T];
     p.fw_dcost[(int64_t)b * na + a] = dsum;
   }
@@ -564,6 +575,8 @@ int fwd_setup(ddp_hip_ctx* ctx) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat2<38>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)sizeof(FwdLat2Lds<38>)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat2<38, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(FwdLat2Lds<38>)));
   }
   return DDP_HIP_OK;
 }
@@ -587,11 +600,16 @@ extern "C" int ddp_hip_rollout(ddp_hip_ctx* ctx) {
   if (!ctx) return DDP_HIP_E_ARG;
   HIP_TRY(hipSetDevice(ctx->device));
   FwdParams p = make_params(ctx);
-  const int bs = 64;
-  const unsigned grid = (unsigned)((ctx->d.batch + bs - 1) / bs);
+  if (fwd_lat_supported(ctx) && getenv("DDP_HIP_FWD_LAT1") == nullptr) {
+    // unconstrained trees of the Talos size: the open-loop form of the latency kernel (one workgroup per instance)
+    hipLaunchKernelGGL((forward_kernel_lat2<38, true>), dim3((unsigned)ctx->d.batch), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+  } else {
+    const int bs = 64;
+    const unsigned grid = (unsigned)((ctx->d.batch + bs - 1) / bs);
 #define CALL(NJ) hipLaunchKernelGGL((rollout_kernel<NJ>), dim3(grid), dim3(bs), 0, ctx->stream, p)
-  DISPATCH_NJ(ctx->d.nv, CALL);
+    DISPATCH_NJ(ctx->d.nv, CALL);
 #undef CALL
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return DDP_HIP_OK;
