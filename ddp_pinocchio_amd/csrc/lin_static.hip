@@ -152,6 +152,12 @@ __device__ __forceinline__ void tau_up_all(const DevModel& m, const double* __re
                                            TauState<T>& s, std::integer_sequence<int, Ks...>) {
   (tau_up<T, T::N - 1 - Ks, QS>(m, qc, vc, tau(T::N - 1 - Ks), s), ...);
 }
+// the joints HI, HI - 1, ..., LO of the leaf -> root pass
+template <class T, int QS, int HI, class TauFn, int... Ks>
+__device__ __forceinline__ void tau_up_range(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc, TauFn tau,
+                                             TauState<T>& s, std::integer_sequence<int, Ks...>) {
+  (tau_up<T, HI - Ks, QS>(m, qc, vc, tau(HI - Ks), s), ...);
+}
 template <class T, int QS, int... Ks>
 __device__ __forceinline__ void tau_down_all(const DevModel& m, const double* __restrict__ qc, const double* __restrict__ vc,
                                              TauState<T>& s, std::integer_sequence<int, Ks...>) {
@@ -188,6 +194,54 @@ __device__ __forceinline__ unsigned int warm_block(const double* base, int lane)
   }
   return sink;
 }
+
+template <class T> constexpr bool parents_at_least(int from, int lo) {
+  for (int k = from; k < T::N; ++k) if (T::parent[k] < lo) return false;
+  return true;
+}
+
+// Two-phase staging of a row's operands (E | r | U | 1/D from the q-cache block, the whole v-cache block): the records of the
+// joints KH .. NV-1 -- where the leaf -> root pass starts -- are waited for and parked first; the loads of the joints 0 .. KH-1
+// are issued at the same time, stay in flight (in registers) while the first half of the pass runs and are parked in front of
+// the second half.  A row wave otherwise spends a quarter of its life waiting for its 17 KB of operands before it does anything.
+template <int NV, int K0, int K1>
+struct StageRegs {
+  static constexpr int NPW = (K1 - K0) * 19, NVW = (K1 - K0) * rbd::VC_STRIDE;
+  static constexpr int CP = (NPW + LBS - 1) / LBS, CV = (NVW + LBS - 1) / LBS;
+  double rp[CP], rv[CV];
+  __device__ __forceinline__ void load(const double* __restrict__ qc, const double* __restrict__ vc, int lane) {
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      int idx = c * LBS + lane;
+      idx = idx < NPW ? idx : NPW - 1;
+      const int K = K0 + idx / 19, e = idx % 19;
+      rp[c] = qc[K * rbd::QC_STRIDE + e];
+    }
+#pragma unroll
+    for (int c = 0; c < CV; ++c) {
+      int idx = c * LBS + lane;
+      idx = idx < NVW ? idx : NVW - 1;
+      rv[c] = vc[K0 * rbd::VC_STRIDE + idx];
+    }
+  }
+  // (no branches: the lanes past the end store the last word again -- control flow in the middle of the evaluation would split
+  // its basic block, and the optimiser then moves it away from its operand loads, see the notes on scalar-path hygiene)
+  __device__ __forceinline__ void park(double* sp, double* sv, int lane) const {
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      int idx = c * LBS + lane;
+      idx = idx < NPW ? idx : NPW - 1;
+      const int K = K0 + idx / 19, e = idx % 19;
+      sp[K * PS + e] = rp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CV; ++c) {
+      int idx = c * LBS + lane;
+      idx = idx < NVW ? idx : NVW - 1;
+      sv[K0 * rbd::VC_STRIDE + idx] = rv[c];
+    }
+  }
+};
 
 __device__ __forceinline__ void tri_index(int64_t q, int Wd, int& ii, int& jj) {   // q -> (ii, jj), ii < jj < Wd, row by row
   int a = (int)floor(((2.0 * Wd - 1.0) - sqrt((2.0 * Wd - 1.0) * (2.0 * Wd - 1.0) - 8.0 * (double)q)) * 0.5);
@@ -454,10 +508,14 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   // scalar path its 76 per-joint reads are 76 serialised L2 round trips per wave (measured: 19.5 -> 17.6 ms at 64 seeds)
   unsigned int w = 0;
   double* s_V = s_P + nv * PS;
+  constexpr int KH = ROWS ? nv / 2 : 0;
+  StageRegs<nv, 0, ROWS ? KH : 1> lower;            // joints 0 .. KH-1: in flight through the first half of the leaf -> root pass
   if constexpr (ROWS) {
-    for (int idx = lane; idx < nv * rbd::VC_STRIDE; idx += LBS) s_V[idx] = vc[idx];
-    stage_placements<nv>(s_P, qc, lane);
-    __syncthreads();
+    StageRegs<nv, KH, nv> upper;
+    upper.load(qc, vc, lane);
+    lower.load(qc, vc, lane);
+    upper.park(s_P, s_V, lane);
+    rbd::coop_sync<true>();                         // one wave per workgroup: LDS is in order, no vmcnt(0) behind this fence
   } else {
     w = warm_block<nv * rbd::VC_STRIDE * 8>(vc, lane);
     w ^= warm_block<nv * rbd::QC_STRIDE * 8>(qc, lane);
@@ -466,7 +524,12 @@ __global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
   TauState<T> s;
   auto tau = [&](int k) { double v = ug[k]; if (k == iu) v = v + eps; if (k == ju) v = v + eps; return v; };
   if constexpr (ROWS) {
-    tau_up_all<T, PS>(m, s_P, s_V, tau, s, std::make_integer_sequence<int, nv>{});
+    // joints nv-1 .. KH+1 only touch records KH .. nv-1 (their own and their parents': checked below), joint KH needs its parent's
+    static_assert(!ROWS || parents_at_least<T>(KH + 1, KH), "the first half of the pass must not reach below record KH");
+    tau_up_range<T, PS, nv - 1>(m, s_P, s_V, tau, s, std::make_integer_sequence<int, nv - 1 - KH>{});
+    lower.park(s_P, s_V, lane);
+    rbd::coop_sync<true>();
+    tau_up_range<T, PS, KH>(m, s_P, s_V, tau, s, std::make_integer_sequence<int, KH + 1>{});
     tau_down_all<T, PS>(m, s_P, s_V, s, std::make_integer_sequence<int, nv>{});
   } else {
     tau_up_all<T, rbd::QC_STRIDE>(m, qc, vc, tau, s, std::make_integer_sequence<int, nv>{});
