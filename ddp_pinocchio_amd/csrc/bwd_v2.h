@@ -350,22 +350,27 @@ __global__ __launch_bounds__(BS4) void bwd_gains2(BwdParams p, int64_t t) {
   const double* Cuu = Cux + m * n;
 
   STAMP(8);
-  for (int i = tid; i < n + m; i += BS4) sQ[i] = Q[i];
-  for (int idx = tid; idx < m * n; idx += BS4) sU[idx % m + (idx / m) * LD] = addc ? Qux[idx] + Cux[idx] : Qux[idx];
-  for (int i = tid; i < (M + 2) * LP; i += BS4) { sL[i] = 0.0; sLt_[i] = 0.0; }
-  if (tid == 0) s_failed = 0;
-  // wave 0: row `lane` of the lower triangle of Q_uu + reg I (ddp_bwd.ipp:104), entry j at a[j]
+  // wave 0 only fetches what the factorisation needs -- its row of Q_uu -- and clears the two images of L itself, so that it can
+  // start the LLT as soon as those 38 words per lane are there; the other seven waves stage Q_x | Q_u and Q_ux meanwhile (they are
+  // first read behind the barrier that follows the factorisation)
   double a[M];
   if (wave == 0) {
+    if (tid == 0) s_failed = 0;
     const double reg = p.reg[b];
+    // row `lane` of the lower triangle of Q_uu + reg I (ddp_bwd.ipp:104), entry j at a[j]
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       double qv_ = 0.0;
       if (lane < m && j <= lane) { qv_ = Quu[lane + j * m]; if (addc) qv_ = qv_ + Cuu[lane + j * m]; qv_ = qv_ + (lane == j ? reg : 0.0); }
       a[j] = qv_;
     }
+    for (int i = lane; i < (M + 2) * LP; i += 64) { sL[i] = 0.0; sLt_[i] = 0.0; }
+  } else {
+    constexpr int BSO = BS4 - 64;
+    const int to = tid - 64;
+    for (int i = to; i < n + m; i += BSO) sQ[i] = Q[i];
+    for (int idx = to; idx < m * n; idx += BSO) sU[idx % m + (idx / m) * LD] = addc ? Qux[idx] + Cux[idx] : Qux[idx];
   }
-  __syncthreads();
   STAMP(9);
   if (wave == 0) {
     // Cholesky, lower triangle only; fail <=> pivot <= 0 (:105).  Per entry the updates arrive in ascending k: the order
