@@ -29,6 +29,11 @@ constexpr int BS5 = 512;   // workgroup size of K5
 constexpr int BS4 = 512;   // workgroup size of K4' (wave 0: LLT, waves 1-2: right-hand sides, all eight: loads and the V update)
 constexpr int CB5 = 32;    // columns of F = [f_x | f_u] per K5 workgroup (two MFMA tiles): 4 workgroups per instance
 
+// workgroup barrier for LDS traffic only: the LDS operations of the wave have been performed, then s_barrier.  Unlike
+// __syncthreads() it does not wait for outstanding global loads (vmcnt), which is the point where a kernel keeps loads in flight
+// across a phase boundary; the compiler still waits for the registers a store needs.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N, int M>
 __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
   constexpr int n = N, m = M, NM = N + M;
@@ -56,16 +61,48 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
   const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
   const double* Vxx = Vx + n;
   STAMP(0);
+  // Two-phase staging.  The first product W = V_xx F(:, block) only needs V_xx and the block's own columns of F: those are
+  // waited for; the other columns of F (cold: written by the linearisation) are requested at the same time, stay in flight in
+  // registers through the first product and are parked in front of the second (D = F^T W needs all of F).
+  constexpr int H2 = N / 2;                        // a column of F in 16-byte words
+  static_assert(N % 2 == 0, "columns are moved in 16-byte words");
+  const int ncolA = (NM - c0) < CB5 ? (NM - c0) : CB5;
+  const f64x2* fx2 = reinterpret_cast<const f64x2*>(p.fx + bt * n * n);
+  const f64x2* fu2 = reinterpret_cast<const f64x2*>(p.fu + bt * n * m);
+  auto fsrc = [&](int col, int k2) -> const f64x2* { return col < n ? fx2 + col * H2 + k2 : fu2 + (col - n) * H2 + k2; };
+  constexpr int NRB = ((NM - 1) * H2 + BS5 - 1) / BS5;          // words per lane of the second phase (at most NM - 1 columns)
+  f64x2 rb[NRB];
+  double lq;
   {
     const f64x2* a = reinterpret_cast<const f64x2*>(Vxx);
     f64x2* d = reinterpret_cast<f64x2*>(s_V);
-    for (int i = tid; i < n * n / 2; i += BS5) d[i] = a[i];
-    const f64x2* fx2 = reinterpret_cast<const f64x2*>(p.fx + bt * n * n);
-    const f64x2* fu2 = reinterpret_cast<const f64x2*>(p.fu + bt * n * m);
     f64x2* f = reinterpret_cast<f64x2*>(s_F);
-    for (int i = tid; i < n * n / 2; i += BS5) f[i] = fx2[i];
-    for (int i = tid; i < n * m / 2; i += BS5) f[n * n / 2 + i] = fu2[i];
-    for (int i = tid; i < n; i += BS5) s_vx[i] = Vx[i];
+    constexpr int NRV = (N * N / 2 + BS5 - 1) / BS5, NRA = (CB5 * H2 + BS5 - 1) / BS5;
+    f64x2 rv[NRV], ra[NRA];
+    const int nA = ncolA * H2, nB = (NM - ncolA) * H2;
+#pragma unroll
+    for (int r = 0; r < NRV; ++r) { const int i = tid + r * BS5; rv[r] = a[i < n * n / 2 ? i : n * n / 2 - 1]; }
+#pragma unroll
+    for (int r = 0; r < NRA; ++r) { int e = tid + r * BS5; e = e < nA ? e : nA - 1; ra[r] = *fsrc(c0 + e / H2, e % H2); }
+    const double vxv = Vx[tid < n ? tid : n - 1];
+    {                                              // the gradient term of the last wave's Q_x | Q_u columns: requested ahead of the
+      const int cq = c0 + lane < NM ? c0 + lane : NM - 1;                  // second phase (a load behind it would wait for all of it)
+      lq = cq < n ? p.lx[bt * n + cq] : p.lu[bt * m + (cq - n)];
+    }
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) {
+      int e = tid + r * BS5;
+      e = e < nB ? e : nB - 1;
+      const int ci = e / H2;
+      rb[r] = *fsrc(ci < c0 ? ci : ci + ncolA, e % H2);
+    }
+#pragma unroll
+    // (branch-free parking: lanes past the end store the last word again; under a branch the optimiser sinks the load into it
+    // and waits for everything in flight)
+    for (int r = 0; r < NRV; ++r) { int i = tid + r * BS5; i = i < n * n / 2 ? i : n * n / 2 - 1; d[i] = rv[r]; }
+#pragma unroll
+    for (int r = 0; r < NRA; ++r) { int e = tid + r * BS5; e = e < nA ? e : nA - 1; f[(c0 + e / H2) * H2 + e % H2] = ra[r]; }
+    s_vx[tid < n ? tid : n - 1] = vxv;
   }
   const double* eqv = p.eq_val + (int64_t)b * Etot + Eo;
   const double* eqx = p.eq_x + ((int64_t)b * Etot + Eo) * n;
@@ -76,7 +113,7 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
   const double* eq_ux = p.eq_ux + ((int64_t)b * Etot + Eo) * m * n;
   const double* eq_uu = p.eq_uu + ((int64_t)b * Etot + Eo) * m * m;
   for (int i = tid; i < e; i += BS5) s_tmp[i] = pe[i] + mu * eqv[i];
-  __syncthreads();
+  lds_barrier();                                     // (LDS only: no vmcnt(0) -- the second phase of F stays in flight)
   STAMP(1);
   double* Q = p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m);
   // Q_x | Q_u of this block's columns (:61-68): l + F^T V_x + multiplier terms -- one lane per column in the last wave (it has
@@ -87,7 +124,7 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
     double sacc = 0.0;
 #pragma unroll 4
     for (int k = 0; k < n; ++k) sacc += col[k] * s_vx[k];
-    double acc = c < n ? p.lx[bt * n + c] : p.lu[bt * m + (c - n)];
+    double acc = lq;
     acc += sacc;
     if (e > 0) {
       double s1 = 0.0, s2 = 0.0;
@@ -121,7 +158,7 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
     }
     wacc[it_] = acc;
   }
-  __syncthreads();                                   // every wave is done reading V_xx: W takes its place
+  lds_barrier();                                     // every wave is done reading V_xx: W takes its place
 #pragma unroll
   for (int it_ = 0; it_ < TPW1; ++it_) {
     const int tile = wave + it_ * NW;
@@ -133,7 +170,18 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
       if (r < n) s_W[r + (16 * ct + l15) * n] = wacc[it_][q];
     }
   }
-  __syncthreads();
+  {                                                  // the rest of F has arrived meanwhile
+    f64x2* f = reinterpret_cast<f64x2*>(s_F);
+    const int nB = (NM - ncolA) * H2;
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) {
+      int e = tid + r * BS5;
+      e = e < nB ? e : nB - 1;
+      const int ci = e / H2;
+      f[(ci < c0 ? ci : ci + ncolA) * H2 + e % H2] = rb[r];
+    }
+  }
+  lds_barrier();
   STAMP(2);
 
   double* Pxx = Q + n + m;
