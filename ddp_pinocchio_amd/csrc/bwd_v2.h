@@ -280,7 +280,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // the round-1 kernel 99 us: both fetch-bound).  Here every elimination is a rolled loop over the pivot whose body has
 // static register indices because the running row / right-hand side is SHIFTED by one entry per step (the pivot is always
 // entry 0): r[p] <- r[p+1] - L(k+1+p, k) r_k.  Entries beyond the triangle meet zero padding of L in LDS.
-constexpr int PHASE = 4;    // columns per phase of the LLT and the substitutions of K4' (even)
+constexpr int PHASE = 2;    // columns per phase of the LLT and the substitutions of K4' (even)
 
 // The column loop of K4's LLT (wave 0, lane = row), in phases of PHASE columns: inside a phase every step updates the W = M - 2 - K0
 // entries of the shifted row that are still alive at the phase's first step (a rolled loop needs one width; with the full
