@@ -427,20 +427,25 @@ __device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int 
       d1k[j] = d1g[kc];
     }
   }
-#pragma unroll 2
-  for (int it = 0; it < NIT; ++it) {
+  // software-pipelined over the column groups: the operands of group it + 1 are requested before group it is formed and stored
+  // (the evaluation's registers are dead here: room for a second operand buffer)
+  double va2[2][NJ], vd2[2][NJ];
+  auto fetch = [&](int it, double (&A)[NJ], double (&D)[NJ]) {
     const int c = it * CG + cg;
-    const bool cv = c < NV;
-    const int cc = cv ? c : NV - 1;
-    const int jp = jb + cc;
-    double va2[NJ], vd2[NJ];
+    const int cc = c < NV ? c : NV - 1;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int k = kk + RW * j;
       const int kc = k < n ? k : n - 1;
-      va2[j] = a2[kc + cc * n];
-      vd2[j] = d2[kc + cc * dstride];
+      A[j] = a2[kc + cc * n];
+      D[j] = d2[kc + cc * dstride];
     }
+  };
+  auto form = [&](int it, const double (&A)[NJ], const double (&D)[NJ]) {
+    const int c = it * CG + cg;
+    const bool cv = c < NV;
+    const int cc = cv ? c : NV - 1;
+    const int jp = jb + cc;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int k = kk + RW * j;
@@ -459,11 +464,20 @@ __device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int 
       }
       double df = fv - f0k[j];                          // difference_out
       df -= eps * a1k[j];
-      df -= eps * va2[j];
+      df -= eps * A[j];
       df *= 2;
-      const double val = 0.5 * (df / eps2 - d1k[j] - vd2[j]);
+      const double val = 0.5 * (df / eps2 - d1k[j] - D[j]);
       out[k + c * n] = val;
       if (mirror) mirror[k + c * mstride] = val;
+    }
+  };
+  fetch(0, va2[0], vd2[0]);
+  for (int it = 0; it < NIT; it += 2) {
+    if (it + 1 < NIT) fetch(it + 1, va2[1], vd2[1]);
+    form(it, va2[0], vd2[0]);
+    if (it + 1 < NIT) {
+      if (it + 2 < NIT) fetch(it + 2, va2[0], vd2[0]);
+      form(it + 1, va2[1], vd2[1]);
     }
   }
 }
