@@ -204,11 +204,11 @@ template <class T> constexpr bool parents_at_least(int from, int lo) {
 // joints KH .. NV-1 -- where the leaf -> root pass starts -- are waited for and parked first; the loads of the joints 0 .. KH-1
 // are issued at the same time, stay in flight (in registers) while the first half of the pass runs and are parked in front of
 // the second half.  A row wave otherwise spends a quarter of its life waiting for its 17 KB of operands before it does anything.
-template <int NV, int K0, int K1>
+template <int NV, int K0, int K1, bool WITH_V = true>
 struct StageRegs {
-  static constexpr int NPW = (K1 - K0) * 19, NVW = (K1 - K0) * rbd::VC_STRIDE;
+  static constexpr int NPW = (K1 - K0) * 19, NVW = WITH_V ? (K1 - K0) * rbd::VC_STRIDE : 0;
   static constexpr int CP = (NPW + LBS - 1) / LBS, CV = (NVW + LBS - 1) / LBS;
-  double rp[CP], rv[CV];
+  double rp[CP], rv[CV > 0 ? CV : 1];
   __device__ __forceinline__ void load(const double* __restrict__ qc, const double* __restrict__ vc, int lane) {
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
@@ -825,7 +825,14 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   // not worth the second code path)
   const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
   if (w == 0x7fc01234u) c.eps = 0.0;     // never true in practice; orders the evaluation behind the warm-up
-  if constexpr (ROWS) { stage_placements<nv>(s_P, c.qc, lane); __syncthreads(); }
+  if constexpr (ROWS) {
+    // all twelve loads per lane in flight at once, then parked (stage_placements' rolled loop is a load -> wait -> store round
+    // trip per iteration: twelve serialised memory latencies at the head of every row wave)
+    StageRegs<nv, 0, nv, false> pl;
+    pl.load(c.qc, c.qc, lane);
+    pl.park(s_P, s_P, lane);
+    rbd::coop_sync<true>();
+  }
   VelState<T> s;
   vel_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
   vel_down_all<T>(c, s, std::make_integer_sequence<int, nv>{});
