@@ -807,10 +807,12 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   // rows: u_i / the accelerations stay in registers, and the staged operands (dead after the acceleration pass) share
   // their LDS with the output stage's buffers (alive after it)
   using Stage = typename std::conditional<ROWS, RowStage<nv>, OutStage<nv>>::type;
-  __shared__ union VelLds { Stage S; double P[ROWS ? nv * PS : 1]; } s_lds;
+  // rows: the whole q-cache block of the row (placements, U, 1/D and the articulated inertias: 12 KB) is staged in LDS, all of
+  // its loads in flight at once; nothing of the evaluation goes through the scalar path's serialised round trips
+  __shared__ union VelLds { Stage S; double P[ROWS ? nv * rbd::QC_STRIDE : 1]; } s_lds;
   Stage& S = s_lds.S;
   double* s_P = s_lds.P;
-  VelCtx<ROWS ? 0 : 1, ROWS ? PS : rbd::QC_STRIDE> c;
+  VelCtx<ROWS ? 0 : 1, rbd::QC_STRIDE> c;
   c.m = p.model;
   c.qc = p.qcache + (bt * (nv + 1) + cfg) * (int64_t)nv * rbd::QC_STRIDE;
   c.qp = ROWS ? s_P : c.qc;
@@ -821,17 +823,18 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
   // pairs: this lane's row of the output stage's acceleration buffer (lane-major, odd stride)
   if constexpr (ROWS) c.uq = nullptr;
   else c.uq = &S.qdd[lane * (nv + 1)];
-  // (staging the articulated inertias of the row in LDS as well -- the whole 12 KB q-cache block -- was measured: 17.2 -> 16.9 ms,
-  // not worth the second code path)
-  const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
-  if (w == 0x7fc01234u) c.eps = 0.0;     // never true in practice; orders the evaluation behind the warm-up
   if constexpr (ROWS) {
-    // all twelve loads per lane in flight at once, then parked (stage_placements' rolled loop is a load -> wait -> store round
-    // trip per iteration: twelve serialised memory latencies at the head of every row wave)
-    StageRegs<nv, 0, nv, false> pl;
-    pl.load(c.qc, c.qc, lane);
-    pl.park(s_P, s_P, lane);
+    constexpr int NW = nv * rbd::QC_STRIDE, CW = (NW + LBS - 1) / LBS;
+    double rq[CW];
+#pragma unroll
+    for (int r = 0; r < CW; ++r) { const int idx = r * LBS + lane; rq[r] = c.qc[idx < NW ? idx : NW - 1]; }
+#pragma unroll
+    for (int r = 0; r < CW; ++r) { const int idx = r * LBS + lane; s_P[idx < NW ? idx : NW - 1] = rq[r]; }
+    c.qc = s_P;
     rbd::coop_sync<true>();
+  } else {
+    const unsigned int w = warm_block<nv * rbd::QC_STRIDE * 8>(c.qc, lane);
+    if (w == 0x7fc01234u) c.eps = 0.0;     // never true in practice; orders the evaluation behind the warm-up
   }
   VelState<T> s;
   vel_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
