@@ -177,16 +177,20 @@ def main():
     ctx = make_instances(capi, a, model, mine, local_rank, T)
     info = ctx.info()
     it = Iterator(ctx, S, a.n_alpha)
-    shard = Shard(capi, dist, torch, rank, world, local_rank, red_dev) if world > 1 else None
+    # (rehearsal on one GPU, backend gloo: RCCL cannot place two ranks on one device -- the exchange goes through shard.best_of)
+    shard = Shard(capi, dist, torch, rank, world, local_rank, red_dev) if (world > 1 and backend == "nccl") else None
 
     def one_iteration(timed):
         it.step(timed)
-        if shard is not None:
+        if world > 1:
             # the one exchange step: best-cost pick over all seeds of all ranks (two 8-byte RCCL all-reduces)
             ctx.cost_seq_aug(0, it.mu)
             costs = ctx.download("COSTS_OLD").sum(axis=1)
             j = int(np.argmin(costs))
-            shard.best(costs[j], mine[j])
+            if shard is not None:
+                shard.best(costs[j], mine[j])
+            else:
+                shard_rule.best_of(costs, mine, device=red_dev)
 
     # HIP events around every launch of the roofline kernel (K3) and of the few-launch kernels; K4's 200 launches per sweep
     # are left out (an event pair costs stream time): its figure below is the backward phase minus K3.  Switched on ahead of
@@ -300,9 +304,10 @@ def main():
         if not a.no_cpu_baseline and a.cpu_iterations > 0:
             out["cpu_baseline"] = cpu_baseline(a, model)
         print(json.dumps(out), flush=True)
-    if shard is not None:
+    if world > 1:
         dist.barrier()          # rank 0 may still be timing the CPU baseline: leave together
-        shard.close()
+        if shard is not None:
+            shard.close()
         dist.destroy_process_group()
 
 
