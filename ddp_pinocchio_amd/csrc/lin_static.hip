@@ -488,7 +488,7 @@ __device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int 
 //   g <  2 nv      : (v_{g-nv}, u_lane)  cfg 0,   vcfg 1+(g-nv) 38 of 64 lanes
 //   g >= 2 nv      : (u_i, u_j) pairs    cfg 0,   vcfg 0        64 pairs per wave
 template <class T, bool ROWS>
-__global__ __launch_bounds__(LBS) void lin_static_tau_kernel(LinParams p) {
+__global__ __launch_bounds__(LBS, ROWS ? 1 : 3) void lin_static_tau_kernel(LinParams p) {
   constexpr int nv = T::N, n = 2 * nv;
   constexpr int TRI = nv * (nv - 1) / 2, GU = (TRI + LBS - 1) / LBS, G = ROWS ? 2 * nv : GU;
   const int64_t bt = blockIdx.x / G;
