@@ -30,11 +30,10 @@ auto ddp_solver_t<Problem>::
 
   double mu = static_cast<double>(backward_pass_result.mu), step = 0;
   // 8 halvings per round, the largest accepted one kept: the decision of the sequential halving (ddp_fwd.ipp:29-64).
-  // Without a line search (do_linesearch == false, :61-63) the reference takes the full step unconditionally: one
-  // candidate, and whatever the cost does the rollout at step 1 is what new_traj holds
-  int rc = ddp_hip_forward(ctx, &mu, do_linesearch ? 8 : 1, &step, nullptr);
+  // Without a line search (do_linesearch == false, :61-63) the reference takes the full step unconditionally:
+  // n_alpha = 0 asks the library for exactly that (one rollout at step 1, accepted whatever the cost does)
+  int rc = ddp_hip_forward(ctx, &mu, do_linesearch ? 8 : 0, &step, nullptr);
   hip_bridge::check(rc, "ddp_hip_forward");                       // rc > 0: step < 1e-10 was reached (:35-37)
-  if (not do_linesearch) step = 1;
 
   hip_bridge::download(ctx, DDP_HIP_SEQ_X_NEW, new_traj_storage.m_state_data);
   hip_bridge::download(ctx, DDP_HIP_SEQ_U_NEW, new_traj_storage.m_control_data);

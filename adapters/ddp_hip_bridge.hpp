@@ -40,8 +40,19 @@ void fill_model(Model const& model, ddp_hip_model& out, ddp_hip_model_storage& s
 template <typename Scalar>
 void fill_model(pendulum_model_t<Scalar> const& model, ddp_hip_model& out, ddp_hip_model_storage& st) {
   check(ddp_hip_builtin_model(DDP_HIP_BUILTIN_PENDULUM, 0, &st, &out), "ddp_hip_builtin_model");
-  out.mass = static_cast<double>(model.m_mass);        // pendulum_model.hpp:24-25
-  out.length = static_cast<double>(model.m_length);
+  // m_mass / m_length are PRIVATE (pendulum_model.hpp:20-26) and the drop-in does not touch the reference's headers: both
+  // are read back through the public dynamics_aba (pendulum_model.hpp:105-115),
+  //   acc(q, v, tau) = -g / length * sin(q) + tau / mass,   g = 9.81 (:26)
+  // probed at (q, tau) = (0, 1) -> 1 / mass and at (pi / 2, 0) -> -g / length
+  using mat_t = Eigen::Matrix<Scalar, 1, 1>;
+  mat_t acc, q, v, tau;
+  v[0] = 0;
+  q[0] = 0; tau[0] = 1;
+  model.dynamics_aba(eigen::as_mut_view(acc), eigen::as_const_view(q), eigen::as_const_view(v), eigen::as_const_view(tau));
+  out.mass = 1.0 / static_cast<double>(acc[0]);
+  q[0] = static_cast<Scalar>(1.5707963267948966192313216916398L); tau[0] = 0;
+  model.dynamics_aba(eigen::as_mut_view(acc), eigen::as_const_view(q), eigen::as_const_view(v), eigen::as_const_view(tau));
+  out.length = -9.81 / static_cast<double>(acc[0]);
 }
 
 // constraint description.  The reference composes constraint types (problem.hpp:527-870); the adapter needs to know which
@@ -128,7 +139,9 @@ auto entry_for(Solver const& solver) -> entry_t& {
   hp.eq_target = target.data();
   set_frame(hp, base);
   // dynamics_t::second_order_finite_diff (problem.hpp:523): true -> mode 2 (:152-298), false -> mode 1 (:67-150).
-  // first_order_deriv is analytic in the reference (problem.hpp:463-503): first_order_fd = 0
+  // first_order_deriv is analytic in the reference (problem.hpp:463-503): first_order_fd = 0.  The library takes this
+  // combination for every vector-space model, constrained or not (lin_analytic.hip: ana_eq_kernel runs the chain rule of
+  // problem.hpp:569-605 and its mode-1 differences :611-620 on the analytic jacobians; K <= 2 time shifts on large trees)
   hp.first_order_fd = 0;
   hp.fd_mode = prob.m_dynamics.second_order_finite_diff ? 2 : 1;
   check(ddp_hip_create(&hp, /*device=*/0, /*flags=*/0, &e.ctx), "ddp_hip_create");

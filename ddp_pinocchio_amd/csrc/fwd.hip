@@ -32,6 +32,7 @@ struct FwdParams {
   double* dcost_acc;
   int32_t* state;
   int32_t n_alpha, round;
+  int32_t no_linesearch, pad_;   // ddp_fwd.ipp:61-63: the full step is taken whatever the cost does
 };
 
 // constraint value at solver time t: constraint_advance_time_t::eval_to (problem.hpp:563-567) applied
@@ -491,7 +492,7 @@ __global__ void select_kernel(FwdParams p) {
       const int cand = p.round * na + a;
       if (cand > 33) break;
       last = a;
-      if (p.fw_dcost[(int64_t)b * na + a] <= 0) { win = a; break; }
+      if (p.no_linesearch || p.fw_dcost[(int64_t)b * na + a] <= 0) { win = a; break; }
     }
     s_win = win;
     s_last = last;
@@ -638,7 +639,10 @@ extern "C" int ddp_hip_cost_seq_aug(ddp_hip_ctx* ctx, int which, const double* m
 }
 
 extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alpha, double* step_out, double* dcost_out) {
-  if (!ctx || !mu || !step_out || n_alpha < 1 || n_alpha > ctx->n_alpha_max) return DDP_HIP_E_ARG;
+  if (!ctx || !mu || !step_out || n_alpha < 0 || n_alpha > ctx->n_alpha_max) return DDP_HIP_E_ARG;
+  // n_alpha == 0: do_linesearch == false (ddp_fwd.ipp:61-63) -- one rollout at step 1, accepted unconditionally
+  const bool no_linesearch = n_alpha == 0;
+  if (no_linesearch) n_alpha = 1;
   const Dims& d = ctx->d;
   const int64_t B = d.batch;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -648,6 +652,7 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
   HIP_TRY(hipMemcpyAsync(ctx->fw_state_d, state.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
   FwdParams p = make_params(ctx);
   p.n_alpha = n_alpha;
+  p.no_linesearch = no_linesearch ? 1 : 0;
   int rc = launch_cost(ctx, p, 0);                                   // ddp_fwd.ipp:24-26
   if (rc != DDP_HIP_OK) return rc;
   const int bs = 64;

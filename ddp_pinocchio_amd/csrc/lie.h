@@ -28,15 +28,36 @@ __device__ __forceinline__ void quat_mul(const double* a, const double* b, doubl
   c[2] = aw * bz + ax * by - ay * bx + az * bw;
   c[3] = aw * bw - ax * bx - ay * by - az * bz;
 }
-// series coefficients in t = |w|: b = (1 - cos t)/t^2, c = (t - sin t)/t^3, d = (1 - t sin t / (2 (1 - cos t)))/t^2
+// coefficients in t = |w|: b = (1 - cos t)/t^2, c = (t - sin t)/t^3, d = (1 - (t/2) cot(t/2))/t^2.  The closed forms cancel
+// near 0 (relative error ~ 6 eps / t^2 for c, 12 eps / t^2 for d: 2e-8 at t = 1e-4, where round 2 switched over), so the
+// Taylor series runs up to t^2 < 0.04 (six terms: truncation < 1e-16) and the closed forms -- written on the half angle, which
+// removes the 1 - cos t cancellation -- take over where they are good to 1e-13.  oracle/ddp_oracle.c:so3_coeffs is the same code.
 __device__ __forceinline__ void so3_coeffs(double t2, double& b, double& c, double& d) {
-  if (t2 < 1e-8) {
-    b = 0.5 - t2 / 24 + t2 * t2 / 720; c = 1.0 / 6 - t2 / 120 + t2 * t2 / 5040; d = 1.0 / 12 + t2 / 720 + t2 * t2 / 30240;
+  if (t2 < 0.04) {
+    b = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 + t2 * (-1.0 / 479001600)))));
+    c = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 + t2 * (-1.0 / 6227020800.0)))));
+    d = 1.0 / 12 + t2 * (1.0 / 720 + t2 * (1.0 / 30240 + t2 * (1.0 / 1209600 + t2 * (1.0 / 47900160 + t2 * (691.0 / 1307674368000.0)))));
+  } else {
+    const double t = sqrt(t2);
+    double st, ct, sh, ch;
+    sincos(t, &st, &ct);
+    sincos(0.5 * t, &sh, &ch);
+    b = 2.0 * sh * sh / t2; c = (t - st) / (t2 * t); d = (1 - 0.5 * t * ch / sh) / t2;
+  }
+}
+// c4 = (1 - t^2/2 - cos t)/t^4, c6 = (t - sin t - t^3/6)/t^5 (Barfoot's Q block): cancellation ~ 24 eps / t^4 resp. 120 eps / t^4,
+// so the series (eight terms) runs up to t^2 < 1
+__device__ __forceinline__ void so3_coeffs_q(double t2, double& c4, double& c6) {
+  if (t2 < 1.0) {
+    c4 = -1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 + t2 * (-1.0 / 479001600 + t2 * (1.0 / 87178291200.0 +
+         t2 * (-1.0 / 20922789888000.0 + t2 * (1.0 / 6402373705728000.0)))))));
+    c6 = -1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 + t2 * (-1.0 / 6227020800.0 + t2 * (1.0 / 1307674368000.0 +
+         t2 * (-1.0 / 355687428096000.0 + t2 * (1.0 / 121645100408832000.0)))))));
   } else {
     const double t = sqrt(t2);
     double st, ct;
     sincos(t, &st, &ct);
-    b = (1 - ct) / t2; c = (t - st) / (t2 * t); d = (1 - t * st / (2 * (1 - ct))) / t2;
+    c4 = (1 - t2 / 2 - ct) / (t2 * t2); c6 = (t - st - t2 * t / 6) / (t2 * t2 * t);
   }
 }
 __device__ __forceinline__ void quat_exp(const double* w, double* qt) {
@@ -115,9 +136,9 @@ __device__ void se3_Jlog(const double* nu, double* J) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) Ji[k] = 0.5 * W[k] + d * W2[k];
   Ji[0] += 1; Ji[4] += 1; Ji[8] += 1;
-  double c4, c5;
-  if (t2 < 1e-6) { c4 = -1.0 / 24 + t2 / 720 - t2 * t2 / 40320; c5 = 0.5 * (c4 - 3 * (-1.0 / 120 + t2 / 5040 - t2 * t2 / 362880)); }
-  else { const double t = sqrt(t2); c4 = (1 - t2 / 2 - cos(t)) / (t2 * t2); c5 = 0.5 * (c4 - 3 * (t - sin(t) - t2 * t / 6) / (t2 * t2 * t)); }
+  double c4, c6;
+  so3_coeffs_q(t2, c4, c6);
+  const double c5 = 0.5 * (c4 - 3 * c6);
   double nW[9], nV[9], WV[9], VW[9], WVW[9], WWV[9], VWW[9], WVWW[9], WWVW[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) { nW[k] = -W[k]; nV[k] = -V[k]; }

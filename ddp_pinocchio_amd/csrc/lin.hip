@@ -759,6 +759,11 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
   const int64_t P = (int64_t)W * (W - 1) / 2;
   const int fd_mode = ctx->model_h.fd_mode;
   const bool small = NJ <= 6;
+  // large trees with analytic first order: the constraint chain runs on the analytic jacobians (lin_analytic.hip:
+  // ana_eq_kernel), and in mode 1 its tensors come out of the same pass over the perturbed points as the dynamics' own
+  const bool ana_large = !small && !ctx->model_h.first_order_fd && ctx->model_h.kind == DDP_HIP_MODEL_TREE;
+  const bool eq_stage = (stages & DDP_HIP_LIN_EQ) && d.Etot > 0;
+  const bool m1_fused = ana_large && fd_mode == 1 && p.has_tensors && eq_stage;   // LIN_SECOND's mode-1 pass is issued by the LIN_EQ stage
   if (stages & DDP_HIP_LIN_COST) hipLaunchKernelGGL(lin_cost_kernel, dim3((unsigned)BT), dim3(64), 0, ctx->stream, p);
   // static-topology path: the q- / v-caches of the mode-2 stencil also serve the first order (base configuration and
   // base (q, v)), so they are built ahead of whichever stage comes first
@@ -779,7 +784,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     hipLaunchKernelGGL((lin_base_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
     if (!ctx->model_h.first_order_fd && ctx->model_h.kind == DDP_HIP_MODEL_TREE) {
       if constexpr (small) hipLaunchKernelGGL((lin_first_analytic_small_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
-      else { const int rc_ = lin_analytic_launch(ctx, p, 0); if (rc_ != DDP_HIP_OK) return rc_; }
+      else { const int rc_ = lin_analytic_launch(ctx, p, 0, LIN_ANA_F); if (rc_ != DDP_HIP_OK) return rc_; }
     } else if (ctx->model_h.first_order_fd) {
       if (ctx->lin_static && p.qcache && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); { const int rc_ = lin_static_launch(ctx, p, 0); if (rc_ != DDP_HIP_OK) return rc_; } }
       else hipLaunchKernelGGL((lin_first_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
@@ -807,9 +812,9 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
         hipLaunchKernelGGL((lin_offdiag_kernel<NJ, 0>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p);
       }
     } else if (fd_mode == 1) {
-      if (ctx->model_h.first_order_fd) return DDP_HIP_E_UNSUPPORTED;  // forward differences of FD jacobians are numerically void
+      if (ctx->model_h.first_order_fd) return DDP_HIP_E_UNSUPPORTED;  // forward differences of FD jacobians are numerically void (refused at ddp_hip_create already)
       if constexpr (small) hipLaunchKernelGGL((second_m1_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
-      else { const int rc_ = lin_analytic_launch(ctx, p, 1); if (rc_ != DDP_HIP_OK) return rc_; }
+      else if (!m1_fused) { const int rc_ = lin_analytic_launch(ctx, p, 1, LIN_ANA_F); if (rc_ != DDP_HIP_OK) return rc_; }
     } else {
       // fd_mode 0: Gauss-Newton variant, tensors are zero
       HIP_TRY(hipMemsetAsync(p.fxx, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_FXX].size * d.batch), ctx->stream));
@@ -818,7 +823,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     }
     prof_end(ctx, DDP_HIP_K_LIN_SECOND);
   }
-  if ((stages & DDP_HIP_LIN_EQ) && d.Etot > 0) {
+  if (eq_stage) {
     if constexpr (small) {
       hipLaunchKernelGGL((eq_first_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
       if (p.has_tensors) {
@@ -833,8 +838,27 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
           HIP_TRY(hipMemsetAsync(p.eq_uu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UU].size * d.batch), ctx->stream));
         }
       }
+    } else if (ana_large) {
+      // analytic jacobians: base point from the resident f_x, f_u, then the tensors
+      { const int rc_ = lin_analytic_launch(ctx, p, 0, LIN_ANA_EQ); if (rc_ != DDP_HIP_OK) return rc_; }
+      if (p.has_tensors) {
+        if (fd_mode == 2) {
+          hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
+          hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p, 1);
+        } else if (fd_mode == 1) {
+          const int fl = LIN_ANA_EQ | ((stages & DDP_HIP_LIN_SECOND) ? LIN_ANA_F : 0);
+          if (fl & LIN_ANA_F) prof_begin(ctx, DDP_HIP_K_LIN_SECOND);
+          const int rc_ = lin_analytic_launch(ctx, p, 1, fl);
+          if (fl & LIN_ANA_F) prof_end(ctx, DDP_HIP_K_LIN_SECOND);
+          if (rc_ != DDP_HIP_OK) return rc_;
+        } else {
+          HIP_TRY(hipMemsetAsync(p.eq_xx, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_XX].size * d.batch), ctx->stream));
+          HIP_TRY(hipMemsetAsync(p.eq_ux, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UX].size * d.batch), ctx->stream));
+          HIP_TRY(hipMemsetAsync(p.eq_uu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UU].size * d.batch), ctx->stream));
+        }
+      }
     } else {
-      // large models: chain rule as three kernels; mode-2 second order reuses the per-point kernel
+      // large models, forward-differenced jacobians: chain rule as three kernels; mode-2 second order reuses the per-point kernel
       if (!p.eq_xk) return DDP_HIP_E_UNSUPPORTED;
       const int K = ctx->model_h.eq_advance;
       if (K < 1) return DDP_HIP_E_UNSUPPORTED;
@@ -846,7 +870,7 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
           hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
           hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p, 1);
         } else if (fd_mode == 1) {
-          return DDP_HIP_E_UNSUPPORTED;
+          return DDP_HIP_E_UNSUPPORTED;   // forward differences of FD jacobians: refused at ddp_hip_create
         } else {
           HIP_TRY(hipMemsetAsync(p.eq_xx, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_XX].size * d.batch), ctx->stream));
           HIP_TRY(hipMemsetAsync(p.eq_ux, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UX].size * d.batch), ctx->stream));
@@ -891,14 +915,15 @@ int lin_setup(ddp_hip_ctx* ctx) {
     }
   }
   {
-    // analytic first order on large trees: its own kernels and workspace; the constraint chain of large models still
-    // differences f at the look-ahead states, which would mix the two kinds of jacobian: refused
-    if (tree && !ctx->model_h.first_order_fd && ctx->d.nv > 6 && ctx->d.Etot > 0) return DDP_HIP_E_UNSUPPORTED;
+    // analytic first order on large trees: its own kernels and workspace (incl. the constraint chain on the analytic
+    // jacobians, lin_analytic.hip: ana_eq_kernel).  Mode 1 on forward-differenced jacobians is numerically void -- eps_mach /
+    // sqrt(eps_mach)^2 = O(1) noise -- and the reference cannot express it (its first order is always analytic): refused here
+    if (ctx->model_h.fd_mode == 1 && ctx->model_h.first_order_fd && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS)) return DDP_HIP_E_UNSUPPORTED;
     const int rc_ = lin_analytic_setup(ctx);
     if (rc_ != DDP_HIP_OK) return rc_;
   }
   // look-ahead states / jacobians of the constraint chain on large models
-  if (ctx->d.Etot > 0 && (ctx->d.nv > 6 || ctx->model_h.ff)) {
+  if (ctx->d.Etot > 0 && (ctx->d.nv > 6 || ctx->model_h.ff) && ctx->model_h.first_order_fd) {
     const Dims& d = ctx->d;
     const int64_t K = ctx->model_h.eq_advance;
     const size_t words = (size_t)(d.batch * d.T * (K * d.nx + (K > 1 ? K - 1 : 0) * d.n * d.n + d.emax * d.n));

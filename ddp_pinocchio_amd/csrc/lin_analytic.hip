@@ -12,6 +12,10 @@
 //   ana_minv_kernel   one wave per (pair, configuration): Cholesky of M and M^-1, rows in registers
 //   ana_out_kernel    one wave per evaluation: -M^-1 T on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), then f_x, f_u
 //                     (p = 0) or the tensor slabs f_xx(:,:,p-1), f_ux(:,:,p-1) = (jacobian' - jacobian) / eps (p > 0)
+//   ana_eq_kernel     (constrained problems) one wave per (pair, direction): the constraint chain
+//                     constraint_advance_time_t::first_order_deriv (problem.hpp:569-605) on the analytic jacobians, at the
+//                     trajectory point (eq_val, eq_x, eq_u) and -- mode 1 -- at x (+) eps e_i, u + eps e_i, differenced into
+//                     eq_xx, eq_ux, eq_uu (problem.hpp:67-150 with Fn = the constraint chain, :611-620)
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
@@ -24,6 +28,7 @@
 namespace {
 
 constexpr int AW = 64;     // lanes per evaluation (one wave)
+constexpr int ANA_F = 1, ANA_EQ = 2;
 
 struct AnaParams {
   LinParams lp;
@@ -32,6 +37,9 @@ struct AnaParams {
   int64_t bt0;      // first (instance, t) pair of the slice
   int32_t nbt;      // pairs in the slice
   int32_t stage;    // 0: first order only (p = 0), 1: the perturbed points (p = 1 .. 2nv)
+  double* Fws;      // [slice pairs][2nv][nv][2nv] the v rows of f_x at the perturbed points (kept for the constraint chain), or null
+  int32_t write_f;  // stage 1: form the f_xx / f_ux slabs (0: this pass only serves the constraint tensors)
+  int32_t pad_;
 };
 
 // ---- kernel A -----------------------------------------------------------------------------------------------------
@@ -317,10 +325,14 @@ __global__ __launch_bounds__(AW) void ana_out_kernel(AnaParams ap) {
         if (j >= N && j - N == r) val = val + 1.0;
         const int64_t off = (N + r) + (int64_t)j * n;
         if (pp == 0) fx[off] = val;
-        else slab_xx[off] = (val - fx[off]) / eps;        // problem.hpp:128-137
+        else {
+          if (ap.write_f) slab_xx[off] = (val - fx[off]) / eps;        // problem.hpp:128-137
+          if (ap.Fws) ap.Fws[(sbt * (2 * N) + (pp - 1)) * (int64_t)N * n + r + (int64_t)j * N] = val;
+        }
       }
     }
   }
+  if (pp > 0 && !ap.write_f) return;
   // the rows of q+ = q + dt v: constants (problem.hpp:487-490), so their differences are exact zeros
   for (int k = lane; k < N * n; k += AW) {
     const int i = k % N, j = k / N;
@@ -338,23 +350,176 @@ __global__ __launch_bounds__(AW) void ana_out_kernel(AnaParams ap) {
   }
 }
 
+// ---- kernel D: the constraint chain on the analytic jacobians -----------------------------------------------------------
+// constraint_advance_time_t::first_order_deriv (problem.hpp:569-605) wrapped K = eq_advance times around a base constraint
+// that depends on q alone (config_constraint_t :744-864, spatial_constraint_t :631-742: jacobian C = [C_q | 0]):
+//   x_{k+1} = f(x_k, u)  (the SAME u at every look-ahead step, :563-567),  eq = c(x_K),
+//   eq_x = C f_x(x_{K-1}) .. f_x(x_0),  eq_u = C f_x(x_{K-1}) .. f_x(x_1) f_u(x_0)                         (:603-604)
+// On a vector-space model the q rows of an analytic f_x are the constants [I | dt I] (:487-490) and C has no v columns, so
+// the first product of the chain, C f_x(x_{K-1}) = [C_q | dt C_q], holds whatever x_{K-1} is: every term the full product
+// adds on top is an exact zero (0 * finite), and the sum the reference forms is reproduced bit for bit without a jacobian at
+// the look-ahead state.  With K <= 2 -- what every reference driver uses -- that is the whole chain (K > 2 would need the
+// full f_x at x_1 .. x_{K-2}: refused at ddp_hip_create).
+// dir = 0: the trajectory point -> eq_val, eq_x, eq_u.  dir = 1 .. n + m (mode 1, problem.hpp:105-147): the point
+// x (+) eps e_i / u + eps e_i -> eq_xx(:,:,i), eq_ux(:,:,i) resp. eq_uu(:,:,i) = (jacobian' - jacobian) / eps.  f_x at a
+// perturbed x comes from ana_out (Fws), f_u there is dt M^-1(q') (Mws); a u direction leaves f_u as it is, bit for bit.
 template <int NJ>
-int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage) {
+__global__ __launch_bounds__(AW) void ana_eq_kernel(AnaParams ap) {
+  const LinParams& p = ap.lp;
+  const DevModel& m = *p.model;
+  const int N = m.nv, n = 2 * N, K = m.eq_advance;
+  const int P = ap.stage == 0 ? 1 : 3 * N;                // directions per pair in this launch
+  const int64_t blk = blockIdx.x;
+  const int64_t sbt = blk / P;
+  const int dir = ap.stage == 0 ? 0 : 1 + (int)(blk % P); // 1 .. 2N: x directions (ana_eval's numbering), 2N+1 .. 3N: u directions
+  const int64_t bt = ap.bt0 + sbt;
+  const int64_t T = p.d.T;
+  const int b = (int)(bt / T);
+  const int64_t t = bt % T;
+  const int e = (int)p.ne[t];
+  if (e == 0) return;
+  const int lane = threadIdx.x;
+  const int64_t Eo = p.Epre[t], Eb = (int64_t)b * p.d.Etot + Eo;
+  const double dt = m.dt;
+  const double eps = sqrt(DBL_EPSILON);
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* s_st = lds;                                   // ABA state
+  double* s_q = s_st + rbd::ABA_LDS_SLOTS * NJ;
+  double* s_v = s_q + NJ;
+  double* s_tau = s_v + NJ;
+  double* s_a = s_tau + NJ;
+  double* s_C = s_a + NJ;                               // C_q: e x nv, column-major
+
+  {
+    const double* xs = p.x + ((int64_t)b * (T + 1) + t) * n;
+    const double* us = p.u + ((int64_t)b * T + t) * N;
+    for (int i = lane; i < N; i += AW) {
+      double qi = xs[i], vi = xs[N + i], ui = us[i];
+      if (dir >= 1 && dir - 1 == i) qi = qi + eps;        // integrate_x / integrate_u, problem.hpp:107,117-118
+      if (dir >= 1 && dir - 1 == N + i) vi = vi + eps;
+      if (dir >= 1 && dir - 1 == 2 * N + i) ui = ui + eps;
+      s_q[i] = qi; s_v[i] = vi; s_tau[i] = ui;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {                           // dynamics_t::eval_to, problem.hpp:441-461
+    rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_st, 0, lane, true);   // ends with a barrier
+    for (int i = lane; i < N; i += AW) {
+      const double vo = dt * s_v[i];
+      s_q[i] = s_q[i] + vo;
+      s_v[i] = s_v[i] + s_a[i] * dt;
+    }
+    __syncthreads();
+  }
+  const double* target = p.target + Eo;
+  double val = 0.0;                                       // lane i < e: row i of the constraint value
+  if (m.eq_kind == DDP_HIP_EQ_CONFIG) {
+    for (int k = lane; k < e * N; k += AW) s_C[k] = (k % e == k / e) ? 1.0 : 0.0;   // d_difference_dq_finish = I (problem.hpp:834-842)
+    if (lane < e) val = s_q[lane] - target[lane];
+  } else {
+    if (lane == 0) {
+      double pos[3], J[3 * NJ];
+      rbd::frame_position<NJ>(m, s_q, pos, J);
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < e; ++i) s_C[i + j * e] = J[i + 3 * j];
+      for (int i = 0; i < e; ++i) s_a[i] = pos[i] - target[i];
+    }
+    __syncthreads();
+    if (lane < e) val = s_a[lane];
+  }
+  __syncthreads();
+  auto C1 = [&](int i, int l) -> double {                 // C f_x(x_{K-1}) = [C_q | dt C_q]; K == 1: C itself
+    if (l < N) return s_C[i + l * e];
+    return K >= 2 ? s_C[i + (l - N) * e] * dt : 0.0;
+  };
+  const double* fx = p.fx + bt * (int64_t)n * n;
+  const double* fu = p.fu + bt * (int64_t)n * N;
+  if (dir == 0) {
+    if (lane < e) p.eq_val[Eb + lane] = val;
+    for (int idx = lane; idx < e * n; idx += AW) {
+      const int i = idx % e, j = idx / e;
+      double sacc = 0.0;
+      for (int l = 0; l < n; ++l) sacc += C1(i, l) * fx[l + (int64_t)j * n];
+      p.eq_x[Eb * n + idx] = sacc;
+    }
+    for (int idx = lane; idx < e * N; idx += AW) {
+      const int i = idx % e, j = idx / e;
+      double sacc = 0.0;
+      for (int l = 0; l < n; ++l) sacc += C1(i, l) * fu[l + (int64_t)j * n];
+      p.eq_u[Eb * N + idx] = sacc;
+    }
+    return;
+  }
+  const double* ox = p.eq_x + Eb * n;
+  const double* ou = p.eq_u + Eb * N;
+  if (dir <= 2 * N) {
+    const int idx3 = dir - 1;                             // the right index of the slab
+    const double* Fv = ap.Fws + (sbt * (2 * N) + idx3) * (int64_t)N * n;                       // v rows of f_x at the perturbed point
+    const double* Mi = ap.Mws + (sbt * (N + 1) + (dir <= N ? dir : 0)) * (int64_t)N * N;       // M^-1 of its configuration
+    double* sxx = p.eq_xx + Eb * n * n + (int64_t)idx3 * e * n;
+    double* sux = p.eq_ux + Eb * N * n + (int64_t)idx3 * e * N;
+    for (int idx = lane; idx < e * n; idx += AW) {
+      const int i = idx % e, j = idx / e;
+      // the q rows of f_x are the constants [I | dt I] (problem.hpp:487-490): one non-zero term, the others exact zeros
+      double sacc = j < N ? C1(i, j) * 1.0 : C1(i, j - N) * (1.0 * dt);
+      for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * Fv[r + (int64_t)j * N];
+      sxx[idx] = (sacc - ox[idx]) / eps;                  // problem.hpp:128-134
+    }
+    for (int idx = lane; idx < e * N; idx += AW) {
+      const int i = idx % e, j = idx / e;
+      double sacc = 0.0;                                  // the q rows of f_u are zero (problem.hpp:493)
+      for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * (Mi[r + (int64_t)j * N] * dt);
+      sux[idx] = (sacc - ou[idx]) / eps;                  // problem.hpp:135-137
+    }
+  } else {
+    const int idx3 = dir - 1 - 2 * N;
+    double* suu = p.eq_uu + Eb * N * N + (int64_t)idx3 * e * N;
+    for (int idx = lane; idx < e * N; idx += AW) {
+      const int i = idx % e, j = idx / e;
+      double sacc = 0.0;
+      for (int l = 0; l < n; ++l) sacc += C1(i, l) * fu[l + (int64_t)j * n];   // f_u(x, u + eps e) == f_u(x, u), bit for bit
+      suu[idx] = (sacc - ou[idx]) / eps;                  // problem.hpp:141-145
+    }
+  }
+}
+
+template <int NJ>
+size_t eq_lds_bytes(const Dims& d) { return sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * NJ + 4 * NJ + d.emax * NJ); }
+
+// flags: ANA_F the dynamics' own outputs (stage 0: f_x, f_u; stage 1: f_xx, f_ux, f_uu), ANA_EQ the constraint chain's
+// (stage 0: eq_val, eq_x, eq_u from the resident f_x, f_u; stage 1: eq_xx, eq_ux, eq_uu)
+template <int NJ>
+int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
   const Dims& d = ctx->d;
   const int64_t BT = d.batch * d.T;
   const int N = (int)d.nv;
   constexpr int R1 = 78 * NJ > rbd::ABA_LDS_SLOTS * NJ ? 78 * NJ : rbd::ABA_LDS_SLOTS * NJ;
   const size_t lds = sizeof(double) * (size_t)(R1 + 30 * NJ + 36 * NJ + 4 * NJ);
+  const bool do_f = (flags & ANA_F) != 0;
+  const bool do_eq = (flags & ANA_EQ) != 0 && d.Etot > 0;
   AnaParams ap{};
   ap.lp = p;
   ap.Tws = ctx->ana_T;
   ap.Mws = ctx->ana_M;
   ap.stage = stage;
-  if (stage == 1) {
+  ap.write_f = do_f ? 1 : 0;
+  ap.Fws = (stage == 1 && do_eq) ? ctx->ana_F : nullptr;
+  if (stage == 1 && do_eq && !ctx->ana_F) return DDP_HIP_E_UNSUPPORTED;
+  if (stage == 1 && do_f) {
     // f_uu is exactly zero (see the header of this file)
     HIP_TRY(hipMemsetAsync(p.fuu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_FUU].size * d.batch), ctx->stream));
   }
   const int P = stage == 0 ? 1 : 2 * N + 1, C = stage == 0 ? 1 : N + 1;
+  if (stage == 0 && !do_f) {
+    // the base point of the constraint chain alone: it reads the resident f_x, f_u
+    if (do_eq) {
+      ap.bt0 = 0; ap.nbt = (int32_t)BT;
+      hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)BT), dim3(AW), eq_lds_bytes<NJ>(d), ctx->stream, ap);
+    }
+    HIP_TRY(hipGetLastError());
+    return DDP_HIP_OK;
+  }
   for (int64_t bt0 = 0; bt0 < BT; bt0 += ctx->ana_nbt) {
     const int64_t nb = BT - bt0 < ctx->ana_nbt ? BT - bt0 : ctx->ana_nbt;
     ap.bt0 = bt0;
@@ -362,6 +527,8 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage) {
     hipLaunchKernelGGL((ana_eval_kernel<NJ>), dim3((unsigned)(nb * P)), dim3(AW), lds, ctx->stream, ap);
     hipLaunchKernelGGL((ana_minv_kernel<NJ>), dim3((unsigned)(nb * C)), dim3(AW), 0, ctx->stream, ap);
     hipLaunchKernelGGL((ana_out_kernel<NJ>), dim3((unsigned)(nb * P)), dim3(AW), 0, ctx->stream, ap);
+    if (do_eq)
+      hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)(nb * (stage == 0 ? 1 : 3 * N))), dim3(AW), eq_lds_bytes<NJ>(d), ctx->stream, ap);
   }
   HIP_TRY(hipGetLastError());
   return DDP_HIP_OK;
@@ -381,6 +548,15 @@ int lin_analytic_setup(ddp_hip_ctx* ctx) {
   // the stage-0 and stage-1 launches of one linearisation share the workspace: the base point keeps slot 0 of every pair
   HIP_TRY(hipMalloc(&ctx->ana_T, sizeof(double) * (size_t)(ctx->ana_nbt * (2 * N + 1) * N * 2 * N)));
   HIP_TRY(hipMalloc(&ctx->ana_M, sizeof(double) * (size_t)(ctx->ana_nbt * (N + 1) * N * N)));
+  if (d.Etot > 0) {
+    // the constraint chain on analytic jacobians (ana_eq_kernel): K <= 2 look-ahead steps, see the kernel's header
+    if (ctx->model_h.eq_advance < 1 || ctx->model_h.eq_advance > 2) return DDP_HIP_E_UNSUPPORTED;
+    if (ctx->model_h.fd_mode == 1 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS))
+      HIP_TRY(hipMalloc(&ctx->ana_F, sizeof(double) * (size_t)(ctx->ana_nbt * 2 * N * N * 2 * N)));
+    const size_t l38 = eq_lds_bytes<38>(d), l64 = eq_lds_bytes<64>(d);
+    if (l38 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ana_eq_kernel<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l38));
+    if (d.nv > 38 && l64 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ana_eq_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l64));
+  }
   constexpr int NJ = 64;
   constexpr int R1 = 78 * NJ > rbd::ABA_LDS_SLOTS * NJ ? 78 * NJ : rbd::ABA_LDS_SLOTS * NJ;
   if (d.nv > 38) {
@@ -393,11 +569,12 @@ int lin_analytic_setup(ddp_hip_ctx* ctx) {
 void lin_analytic_teardown(ddp_hip_ctx* ctx) {
   if (ctx->ana_T) (void)hipFree(ctx->ana_T);
   if (ctx->ana_M) (void)hipFree(ctx->ana_M);
+  if (ctx->ana_F) (void)hipFree(ctx->ana_F);
 }
 
-int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage) {
+int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
   if (!ctx->ana_T || !ctx->ana_M) return DDP_HIP_E_UNSUPPORTED;
   if (stage == 1 && !p.has_tensors) return DDP_HIP_OK;
-  if (ctx->d.nv <= 38) return launch_t<38>(ctx, p, stage);
-  return launch_t<64>(ctx, p, stage);
+  if (ctx->d.nv <= 38) return launch_t<38>(ctx, p, stage, flags);
+  return launch_t<64>(ctx, p, stage, flags);
 }

@@ -32,4 +32,6 @@ int64_t lin_static_ws_per_bt(const DevModel& m);
 // trajectory points (problem.hpp:463-503), stage 1 = forward differences of those jacobians (problem.hpp:67-150)
 int lin_analytic_setup(ddp_hip_ctx* ctx);
 void lin_analytic_teardown(ddp_hip_ctx* ctx);
-int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage);
+// flags: LIN_ANA_F the dynamics' outputs, LIN_ANA_EQ the constraint chain's (problem.hpp:569-620 on the analytic jacobians)
+constexpr int LIN_ANA_F = 1, LIN_ANA_EQ = 2;
+int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags);

@@ -239,13 +239,13 @@ struct ddp_solver_t {   // ddp.hpp:300-869
   template <method M>
   scalar_t forward_pass(trajectory_t& new_traj_storage, trajectory_t const& reference_traj, multiplier_seq_t const& old_mults,
                         backward_pass_result_t<M> const& bres, bool do_linesearch = true) const {
-    (void)do_linesearch;
     upload_traj(reference_traj, DDP_HIP_SEQ_X, DDP_HIP_SEQ_U);
     upload_traj(new_traj_storage, DDP_HIP_SEQ_X_NEW, DDP_HIP_SEQ_U_NEW);
     upload_affine(old_mults, DDP_HIP_SEQ_MULT_ORIGIN, DDP_HIP_SEQ_MULT_VAL, DDP_HIP_SEQ_MULT_JAC);
     upload_affine(bres.feedback, DDP_HIP_SEQ_FB_ORIGIN, DDP_HIP_SEQ_FB_VAL, DDP_HIP_SEQ_FB_JAC);
     double mu = bres.mu, step = 0;
-    check(ddp_hip_forward(ctx, &mu, 8, &step, nullptr), "forward");
+    // do_linesearch == false (ddp_fwd.ipp:61-63): n_alpha = 0, the full step taken unconditionally
+    check(ddp_hip_forward(ctx, &mu, do_linesearch ? 8 : 0, &step, nullptr), "forward");
     check(ddp_hip_download(ctx, DDP_HIP_SEQ_X_NEW, new_traj_storage.m_state_data.data(), 0, 1), "download");
     check(ddp_hip_download(ctx, DDP_HIP_SEQ_U_NEW, new_traj_storage.m_control_data.data(), 0, 1), "download");
     return step;

@@ -160,7 +160,9 @@ int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io, int64_t* r
  * candidates 2^0 .. 2^-(n_alpha-1) roll out concurrently, the LARGEST accepted one is kept (the same
  * decision sequential halving makes); if none is accepted the next n_alpha candidates follow, until
  * step < 1e-10.  mu: host [batch]; step_out: host [batch]; dcost_out: host [batch] or NULL
- * (sum_t(cost_new - cost_old) of the returned step).  X_NEW[0] must hold x_0 (ddp.hpp:752). */
+ * (sum_t(cost_new - cost_old) of the returned step).  X_NEW[0] must hold x_0 (ddp.hpp:752).
+ * n_alpha == 0: do_linesearch == false (ddp_fwd.ipp:61-63) -- the full step is rolled out once and taken whatever the
+ * cost does (step_out = 1, X_NEW / U_NEW = that rollout). */
 int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alpha, double* step_out, double* dcost_out);
 
 /* cost_seq_aug (ddp.hpp:699-735) of (X,U) [which=0] or (X_NEW,U_NEW) [which=1] into COSTS_OLD / COSTS_NEW */

@@ -79,6 +79,8 @@ def lib(path=None):
     L.orc_model_nq.restype = C.c_int32
     L.orc_model_nq.argtypes = [C.POINTER(OrcModel)]
     L.orc_integrate.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp]
+    L.orc_so3_coeffs.argtypes = [C.c_double, _dp]
+    L.orc_so3_coeffs.restype = None
     L.orc_difference.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp]
     for _n in ("orc_d_integrate_dq", "orc_d_integrate_dv", "orc_d_difference_dq_start", "orc_d_difference_dq_finish"):
         getattr(L, _n).argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp]

@@ -105,6 +105,8 @@ void orc_frame_jacobian(const orc_model* m, int32_t joint, const double* off, co
 
 /* ---- Lie-group configurations (pinocchio_model.ipp:222-321); nq = nv + 1 with a free-flyer root, else nq = nv ---- */
 int32_t orc_model_nq(const orc_model* m);
+/* test hook: {sin t/t, (1-cos t)/t^2, (t-sin t)/t^3, (1-(t/2)cot(t/2))/t^2, (1-t^2/2-cos t)/t^4, (t-sin t-t^3/6)/t^5} at t^2 */
+void orc_so3_coeffs(double t2, double* out6);
 void orc_integrate(const orc_model* m, const double* q, const double* v, double* out_q);
 void orc_difference(const orc_model* m, const double* q_start, const double* q_finish, double* out_v);
 void orc_d_integrate_dq(const orc_model* m, const double* q, const double* v, double* out /* nv x nv col-major */);

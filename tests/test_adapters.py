@@ -88,3 +88,58 @@ def test_urdf_reader_builds_and_reads_a_small_arm(tmp_path):
                            os.path.join(ROOT, "host", "test_urdf.cpp"), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode()
     assert "test_urdf: ok" in out
+
+
+# ---- access specifiers of the reference members the adapters name -------------------------------------------------------
+import json
+import sys
+
+GOLDEN_ACCESS = os.path.join(ROOT, "tests", "golden", "reference_member_access.json")
+REFERENCE = "/root/reference"
+
+
+def _access_table():
+    return json.load(open(GOLDEN_ACCESS))
+
+
+def test_reference_member_access_table_is_current():
+    """tests/golden/reference_member_access.json (made by tools/reference_member_access.py) still matches the reference's
+    headers where they are readable (this container); on a box without /root/reference the committed table stands"""
+    if not os.path.isdir(os.path.join(REFERENCE, "include", "ddp")):
+        import pytest
+        pytest.skip("the reference's headers are not on this machine")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import reference_member_access as rma
+    assert rma.table(REFERENCE) == _access_table()
+
+
+def test_adapters_only_name_public_members_of_the_reference():
+    """Round 2's bridge read pendulum_model_t::m_mass / m_length, which are private (pendulum_model.hpp:20-26): a compile
+    error nobody could see here.  Every `.m_xxx` / `->m_xxx` the free functions of the bridge and the two .ipp files name
+    must be a member the table knows as public; the B2 translation unit defines model_t<double>'s own members and may
+    name that class's private members, nothing else's."""
+    table = _access_table()
+    assert all(r["access"] in ("public", "private", "protected") for r in table), [r for r in table if r["access"] is None]
+    public = {r["member"] for r in table if r["access"] == "public"}
+    private = {r["member"] for r in table if r["access"] != "public"}
+    assert {"m_mass", "m_length"} <= private            # the table sees what round 2 missed
+    for rel in ("adapters/ddp_hip_bridge.hpp", "adapters/ddp/ddp_bwd.ipp", "adapters/ddp/ddp_fwd.ipp"):
+        text = _strip_comments(open(os.path.join(ROOT, rel)).read())
+        named = set(re.findall(r"(?:\.|->)\s*(m_[a-z_0-9]+)\b", text))
+        for member in sorted(named):
+            assert member in public or member in private, f"{rel}: {member} is not in tools/reference_member_access.py:USED"
+            # a name that is private in one struct and public in another (m_model: dynamics_t vs model_t) is judged by the
+            # struct it is reached through: the bridge only reaches m_model through dynamics_t::m_model (public)
+            if member in private and member not in public:
+                raise AssertionError(f"{rel}: names the private member {member} of the reference")
+    # the other reference members the bridge reaches (non m_ names): all public
+    for member in ("prob", "eq_idx", "index_begin", "index_end", "dt", "c", "second_order_finite_diff", "lfx", "lfxx",
+                   "dynamics_aba"):
+        assert member in public, member
+
+
+def test_integration_md_listings_are_literal_excerpts():
+    """INTEGRATION.md's listings had drifted from the adapter files in round 2; they are now written from the files
+    (tools/sync_integration.py) and held to them here"""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "sync_integration.py"), "--check"]).decode()
+    assert "listings match" in out and int(out.split()[0]) >= 5

@@ -15,8 +15,8 @@ from test_dynamics_parity import DERIV_SEQS, TENSOR_SEQS, _upload_traj
 EPS, E1 = 2.220446049250313e-16, 1.4901161193847656e-08
 
 
-def _check_linearize(capi, name, T, traj, ulps=8, batch=1):
-    model, spec, o = make(name, T, fd_mode=1, first_order_fd=0, batch=batch)
+def _check_linearize(capi, name, T, traj, ulps=8, batch=1, fd_mode=1):
+    model, spec, o = make(name, T, fd_mode=fd_mode, first_order_fd=0, batch=batch)
     x0, us, xs = traj(o, model)
     d = o.compute_derivatives(xs, us)
     with capi.Context(spec) as ctx:
@@ -44,6 +44,8 @@ def _check_linearize(capi, name, T, traj, ulps=8, batch=1):
                     assert err <= 1e-12 * scale, (key, err)
                 elif key in ("fx", "fu", "eq_x", "eq_u"):
                     assert err <= 1e-10 * scale, (key, err, scale)                       # analytic: the north star's 1e-10
+                elif fd_mode != 1:
+                    continue                                                            # mode-2 tensors: test_dynamics_parity.py's FD-noise bounds
                 elif key in ("fxx", "fux", "fuu"):
                     assert err <= ulps * EPS * cond * jscale / E1, (key, err, ulps * EPS * cond * jscale / E1)
                 else:                                                                   # eq tensors: two chained linearisations
@@ -172,3 +174,77 @@ def test_model_point_evaluations(gpu, which):
         p3, J = h.frame(joint, off, q)
         assert rel_err(p3, o.frame_position(joint, off, q)) < 1e-13
         assert float(np.max(np.abs(J - o.frame_jacobian(joint, off, q)))) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T,fd_mode", [("tree38_config", 3, 1), ("tree38_frame", 4, 1), ("tree38_config", 3, 2), ("tree38_frame", 4, 0)])
+def test_analytic_linearize_talos_constrained(gpu, name, T, fd_mode):
+    """What adapters/ddp_hip_bridge.hpp asks for on every reference driver -- analytic first order (problem.hpp:463-503),
+    FD mode 1 (dy{model, 0.01, false}, test/pinocchio_ddp.cpp:60) and a constraint under two constraint_advance_time_t
+    wrappers -- at the Talos size (round 2 refused it: lin.hip:849,896).  The chain rule runs on the analytic jacobians
+    (lin_analytic.hip: ana_eq_kernel), its mode-1 tensors are forward differences of the chained jacobians
+    (problem.hpp:611-620).  eq_x / eq_u to 1e-10, tensors at the cond(M) noise floor of mode 1 in double."""
+    _check_linearize(gpu, name, T, lambda o, model: held_trajectory(o, model, seed=13, u_sigma=0.3), fd_mode=fd_mode)
+
+
+@pytest.mark.gpu
+def test_analytic_linearize_talos_constrained_slices(gpu):
+    """the same over more (instance, t) pairs than one workspace slice holds (DDP_HIP_ANA_BT pairs, 256 by default):
+    2 instances x T = 150; the oracle is evaluated at picked pairs, one of them the constrained step of the frame problem"""
+    capi = gpu
+    T, B = 150, 2
+    model, spec, o = make("tree38_frame", T, batch=B, fd_mode=1, first_order_fd=0)
+    trajs = [held_trajectory(o, model, seed=90 + b, u_sigma=0.3) for b in range(B)]
+    n, m, nx, e = o.n, o.m, o.nx, 3
+    with capi.Context(spec) as ctx:
+        ctx.upload("X", np.stack([tr[2] for tr in trajs])); ctx.upload("U", np.stack([tr[1] for tr in trajs]))
+        ctx.linearize()
+        got = {(k, b): ctx.download(sq, b, 1)[0] for b in range(B)
+               for k, sq in (("eq_val", "EQ_VAL"), ("eq_x", "EQ_X"), ("eq_u", "EQ_U"), ("eq_xx", "EQ_XX"), ("eq_ux", "EQ_UX"), ("eq_uu", "EQ_UU"),
+                             ("fx", "FX"), ("fxx", "FXX"))}
+    # oracle on a 2-step problem whose constrained step (t = T' - 2 = 0) is the picked pair
+    for b in range(B):
+        _, _, op = make("tree38_frame", 2, fd_mode=1, first_order_fd=0)
+        t = T - 2
+        xs_p = np.zeros(3 * nx); us_p = np.zeros(2 * m)
+        xs_p[:nx] = trajs[b][2][t * nx:(t + 1) * nx]; us_p[:m] = trajs[b][1][t * m:(t + 1) * m]
+        xs_p[nx:2 * nx] = trajs[b][2][(t + 1) * nx:(t + 2) * nx]; us_p[m:] = trajs[b][1][(t + 1) * m:(t + 2) * m]
+        d = op.compute_derivatives(xs_p, us_p)
+        jscale = max(1.0, float(np.max(np.abs(d["fx"]))), float(np.max(np.abs(d["fu"]))))
+        cond = float(np.linalg.cond(op.crba(xs_p[:model.nv])))
+        for key, sz in (("eq_val", e), ("eq_x", e * n), ("eq_u", e * m), ("eq_xx", e * n * n), ("eq_ux", e * m * n), ("eq_uu", e * m * m)):
+            a, r = got[key, b][:sz], d[key][:sz]
+            err, scale = float(np.max(np.abs(a - r))), max(1.0, float(np.max(np.abs(r))))
+            tol = 1e-12 * scale if key == "eq_val" else (1e-10 * scale if key in ("eq_x", "eq_u") else 64 * EPS * cond * jscale * scale / E1)
+            assert np.all(np.isfinite(a)) and err <= tol, (key, b, err, tol)
+        a, r = got["fx", b][t * n * n:(t + 1) * n * n], d["fx"][:n * n]
+        assert float(np.max(np.abs(a - r))) <= 1e-10 * max(1.0, float(np.max(np.abs(r))))
+        a, r = got["fxx", b][t * n ** 3:(t + 1) * n ** 3], d["fxx"][:n ** 3]
+        assert float(np.max(np.abs(a - r))) <= 8 * EPS * cond * jscale / E1
+
+
+@pytest.mark.gpu
+def test_analytic_whole_solve_talos_drivers_mode(gpu):
+    """test/pinocchio_ddp.cpp's exact configuration at the Talos size: config constraint on every joint at every step under
+    two constraint_advance_time_t wrappers, dy{model, 0.01, false} = analytic first order + FD mode 1 -- what the bridge
+    (adapters/ddp_hip_bridge.hpp) requests.  Logs (iterations, mu, reg) must agree with the oracle's solve; trajectories to the
+    mode-1 noise (see test_analytic_whole_solve_chain)."""
+    from ddp_pinocchio_amd import solver
+    capi = gpu
+    T, iters, thr, mu, w, n = 6, 5, 1e-6, 1e4, 1e-1, 10.0
+    model, spec, o = make("tree38_config", T, batch=1, fd_mode=1, first_order_fd=0)
+    rng = np.random.default_rng(5)
+    seed = 0.01 * rng.normal(size=o.Etot * o.n)
+    us0 = 0.01 * np.random.default_rng(41).normal(size=T * model.nv)
+    xs0 = o.rollout(np.zeros(2 * model.nv), us0)
+    xs_ref, us_ref, fb_ref, log_ref = o.solve(xs0, us0, seed, max_iterations=iters, threshold=thr, mu=mu, reg=0.0, w=w, n=n)
+    with capi.Context(spec) as ctx:
+        assert ctx.info()["first_order"] == 2
+        ctx.upload("X", xs0); ctx.upload("U", us0); ctx.upload("X_NEW", xs0); ctx.upload("U_NEW", us0)
+        ctx.upload("MULT_ORIGIN", xs0[:T * o.nx]); ctx.upload("MULT_VAL", np.zeros(o.Etot)); ctx.upload("MULT_JAC", seed)
+        log = solver.solve(ctx, iters, thr, mu, 0.0, w, n)
+        xs, us = ctx.download("X")[0], ctx.download("U")[0]
+    assert int(log["iterations"][0]) == log_ref["iterations"] and bool(log["done"][0]) == bool(log_ref["result"] == 1)
+    assert log["mu"][0] == log_ref["mu"] and log["reg"][0] == log_ref["reg"]
+    assert float(np.max(np.abs(xs - xs_ref))) < 2e-2, float(np.max(np.abs(xs - xs_ref)))
+    assert float(np.max(np.abs(us - us_ref))) < 2.0 * max(1.0, float(np.max(np.abs(us_ref))))

@@ -123,6 +123,68 @@ def test_se3_against_matrix_exponential():
         assert np.allclose(d[6:], q1[7:] - q0[7:], rtol=0, atol=1e-15)
 
 
+def test_so3_series_coefficients_against_mpmath():
+    """The closed forms of (1 - cos t)/t^2, (t - sin t)/t^3, (1 - (t/2) cot(t/2))/t^2, (1 - t^2/2 - cos t)/t^4 and
+    (t - sin t - t^3/6)/t^5 cancel near t = 0: round 2 switched from the series to them at t = 1e-4 / 1e-3, where they are only
+    good to 2e-8 / 3e-5 (d = 0.337 instead of 0.08333 at t = 1.0001e-4).  Rotation increments of 1e-4 .. 1e-2 rad are what
+    se3_difference (forward pass, optimality) and Jlog6 (update_origin) see near convergence.  Swept over t = 1e-6 .. pi
+    against mpmath at 50 digits: every coefficient to 5e-13 relative (device code = the same lines, csrc/lie.h)."""
+    import ctypes as C
+    import mpmath as mp
+    from oracle.binding import lib
+    mp.mp.dps = 50
+    L = lib()
+    out = (C.c_double * 6)()
+    ts = np.concatenate([np.logspace(-6, np.log10(3.1), 140), [1.0001e-4, 1e-3, 3e-3, 0.2 - 1e-9, 0.2 + 1e-9, 1 - 1e-9, 1 + 1e-9]])
+    worst = np.zeros(6)
+    for t_ in ts:
+        t = mp.mpf(float(t_))
+        t2 = float(t_) * float(t_)
+        tt = mp.sqrt(mp.mpf(t2))                              # the functions are evaluated at the t^2 the code receives
+        ref = [mp.sin(tt) / tt, (1 - mp.cos(tt)) / tt**2, (tt - mp.sin(tt)) / tt**3, (1 - (tt / 2) * mp.cot(tt / 2)) / tt**2,
+               (1 - tt**2 / 2 - mp.cos(tt)) / tt**4, (tt - mp.sin(tt) - tt**3 / 6) / tt**5]
+        L.orc_so3_coeffs(t2, out)
+        for k in range(6):
+            worst[k] = max(worst[k], abs(float((mp.mpf(out[k]) - ref[k]) / ref[k])))
+    assert np.all(worst < 5e-13), worst
+
+
+def test_se3_difference_and_jlog_at_small_rotations():
+    """difference and d_difference_dq_finish (Jlog6) for rotation increments from 1e-6 to 1e-1 rad, against mpmath's generic
+    logm at 50 digits and central differences of it -- the range where round 2's thresholds lost eight digits"""
+    import mpmath as mp
+    mp.mp.dps = 50
+    bm, o = _oracle(3)
+    rng = np.random.default_rng(11)
+    for ang in (1e-6, 1.0001e-4, 1e-3, 3e-3, 1e-2, 1e-1):
+        q0 = random_state(bm, rng)[:bm.nq]
+        v = np.zeros(bm.nv)
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        v[:3] = rng.normal(size=3) * 0.3
+        v[3:6] = ang * axis
+        q1 = o.integrate(q0, v)
+        d = o.difference(q0, q1)
+        Lg = mp.logm(mp.inverse(_hom(q0)) * _hom(q1))
+        ref = np.array([float(mp.re(Lg[0, 3])), float(mp.re(Lg[1, 3])), float(mp.re(Lg[2, 3])),
+                        float(mp.re(Lg[2, 1])), float(mp.re(Lg[0, 2])), float(mp.re(Lg[1, 0]))])
+        # q1 itself carries the rounding of one quaternion product (1e-16 absolute on a unit quaternion)
+        assert np.max(np.abs(d[:6] - ref)) < 2e-15 + 1e-13 * np.max(np.abs(ref)), (ang, np.max(np.abs(d[:6] - ref)))
+        assert np.max(np.abs(d[:6] - v[:6])) < 5e-15, (ang, np.max(np.abs(d[:6] - v[:6])))
+        # Jlog6 against central differences of the mpmath logarithm (right perturbations of q1)
+        J = o.d_difference_dq_finish(q0, q1)[:6, :6]
+        h = mp.mpf(10) ** -20
+        M0i, M1 = mp.inverse(_hom(q0)), _hom(q1)
+        for j in range(6):
+            e = np.zeros(6); e[j] = 1.0
+            E = _hat(e)
+            Lp = mp.logm(M0i * M1 * mp.expm(E * h, method="pade"))
+            Lm = mp.logm(M0i * M1 * mp.expm(E * (-h), method="pade"))
+            col = [(Lp[0, 3] - Lm[0, 3]) / (2 * h), (Lp[1, 3] - Lm[1, 3]) / (2 * h), (Lp[2, 3] - Lm[2, 3]) / (2 * h),
+                   (Lp[2, 1] - Lm[2, 1]) / (2 * h), (Lp[0, 2] - Lm[0, 2]) / (2 * h), (Lp[1, 0] - Lm[1, 0]) / (2 * h)]
+            col = np.array([float(mp.re(c)) for c in col])
+            assert np.max(np.abs(J[:, j] - col)) < 1e-12, (ang, j, np.max(np.abs(J[:, j] - col)))
+
+
 def test_se3_known_answers():
     """pinocchio's documented conventions: translation is applied in the body frame, quaternion stored x, y, z, w"""
     bm, o = _oracle(3)
