@@ -5,14 +5,19 @@ One "step" = one full DDP iteration of every resident instance on this GPU:
     linearise (first-order jacobians + second-order tensors)  ->  backward sweep (with tensors)
     ->  forward sweep with 8 batched line-search steps  ->  swap trajectories (+ the reg rule of ddp.hpp:819-824)
 with all inputs resident in HBM.  Independent instances (random control seeds) are sharded across ranks with no
-data-path collective; the only exchange is the best-cost pick: two 8-byte RCCL all-reduces per step through the
-library's own ddp_hip_shard_best (csrc/comm.cpp).
+data-path collective; the only exchange is the best-cost pick: the local argmin on the device, ONE 16-byte RCCL all-gather
+and the argmin of the G pairs on the device again (ddp_hip_shard_pick, csrc/comm.cpp) -- the N = 1 line runs the same pick
+without the collective, so the lines are comparable.  `python3 bench.py --gpus N` without a launcher starts its N ranks
+itself (fresh child processes, before anything in the parent touches a GPU).
 
 Workloads (BASELINE.json configs):
     default                --seeds-per-gpu 64   config 4 at N = 1 / weak scaling ("scaling": "weak")
     --total-seeds 64       config 4 as worded: 64 seeds in total over the N ranks ("scaling": "strong")
     --seeds-per-gpu 1      config 3: one instance x 8 line-search alphas
-The default run also times config 3 for a few iterations after the timed region and prints it under `extra`.
+The default run also times, after the timed region and under `extra`: config 3 (one instance), and the CONSTRAINED problem
+classes the headline's data never reach (its value function is identically zero: DESIGN.md 4d) -- `constrained_frame`
+(config 5's inputs: 3-row frame constraint at T-2, N(0,1)-seeded multiplier jacobians, mu = 1e3) and `constrained_config`
+(test/pinocchio_ddp.cpp's shape at the Talos size: e = 38 at every step) -- V != 0, K != 0, the line search halves.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the library's own stream;
 `cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithm) on a bounded sample.
@@ -71,31 +76,12 @@ def parse():
     return ap.parse_args()
 
 
-class Shard:
-    """The library's RCCL communicator (ddp_hip_comm_*, csrc/comm.cpp); the 128-byte id travels over torch.distributed."""
-
-    def __init__(self, capi, dist, torch, rank, world, device, red_dev):
-        import ctypes as C
-        self.C, self.L = C, capi.lib()
-        uid = (C.c_ubyte * 128)()
-        if rank == 0:
-            assert self.L.ddp_hip_comm_unique_id(uid) == 0
-        t = torch.tensor(list(uid), dtype=torch.uint8, device=red_dev)
-        dist.broadcast(t, src=0)
-        uid = (C.c_ubyte * 128)(*t.cpu().tolist())
-        self.comm = C.c_void_p()
-        rc = self.L.ddp_hip_comm_init(uid, rank, world, device, C.byref(self.comm))
-        assert rc == 0, f"ddp_hip_comm_init: {rc}"
-
-    def best(self, cost, gidx):
-        C = self.C
-        c, i = C.c_double(), C.c_int64()
-        rc = self.L.ddp_hip_shard_best(self.comm, float(cost), int(gidx), C.byref(c), C.byref(i))
-        assert rc == 0, f"ddp_hip_shard_best: {rc}"
-        return c.value, i.value
-
-    def close(self):
-        self.L.ddp_hip_comm_destroy(self.comm)
+def make_comm(capi, dist, torch, rank, world, device, red_dev):
+    """The library's RCCL communicator (capi.Comm, csrc/comm.cpp); the 128-byte id travels over torch.distributed."""
+    uid = capi.Comm.unique_id() if rank == 0 else bytes(128)
+    t = torch.tensor(list(uid), dtype=torch.uint8, device=red_dev)
+    dist.broadcast(t, src=0)
+    return capi.Comm(bytes(t.cpu().tolist()), rank, world, device)
 
 
 def make_instances(capi, a, model, seeds, device, T):
@@ -140,8 +126,32 @@ class Iterator:
             self.phase_ms["forward"] += (t3 - t2) * 1e3
 
 
+def spawn_ranks(a):
+    """`python3 bench.py --gpus N` with no launcher around it: start the N ranks as fresh child processes -- the parent has
+    not imported torch nor touched a GPU, and it never execs -- relay rank 0's JSON line and leave with the worst exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     import torch
     import torch.distributed as dist
     from ddp_pinocchio_amd import capi
@@ -150,7 +160,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     # rehearsal knobs (development only): DDP_BENCH_BACKEND=gloo and DDP_BENCH_SINGLE_DEVICE=1 run the N > 1 code path
     # with every rank on GPU 0 of a one-GPU box; the driver's multi-GPU runs use the defaults (nccl = RCCL, one GPU per rank)
     backend = os.environ.get("DDP_BENCH_BACKEND", "nccl")
@@ -178,19 +189,18 @@ def main():
     info = ctx.info()
     it = Iterator(ctx, S, a.n_alpha)
     # (rehearsal on one GPU, backend gloo: RCCL cannot place two ranks on one device -- the exchange goes through shard.best_of)
-    shard = Shard(capi, dist, torch, rank, world, local_rank, red_dev) if (world > 1 and backend == "nccl") else None
+    comm = make_comm(capi, dist, torch, rank, world, local_rank, red_dev) if (world > 1 and backend == "nccl") else None
+    picks = []
 
     def one_iteration(timed):
         it.step(timed)
-        if world > 1:
-            # the one exchange step: best-cost pick over all seeds of all ranks (two 8-byte RCCL all-reduces)
-            ctx.cost_seq_aug(0, it.mu)
-            costs = ctx.download("COSTS_OLD").sum(axis=1)
-            j = int(np.argmin(costs))
-            if shard is not None:
-                shard.best(costs[j], mine[j])
-            else:
-                shard_rule.best_of(costs, mine, device=red_dev)
+        # the one exchange step: best-cost pick over all seeds of all ranks.  Local argmin on the device, one 16-byte
+        # all-gather, argmin of the G pairs (ddp_hip_shard_pick); with one rank the same device work and no collective
+        if comm is not None or world == 1:
+            picks.append(ctx.shard_pick(comm))
+        else:   # gloo rehearsal with every rank on one GPU: the host mirror of the same rule
+            total_cost = ctx.download("COSTS_OLD").sum(axis=1)
+            picks.append(shard_rule.pick(total_cost, rank, world, device=red_dev))
 
     # HIP events around every launch of the roofline kernel (K3) and of the few-launch kernels; K4's 200 launches per sweep
     # are left out (an event pair costs stream time): its figure below is the backward phase minus K3.  Switched on ahead of
@@ -290,6 +300,8 @@ def main():
             "uninstrumented": None if plain_ms is None else {
                 **plain_ms, "iterations_per_s_this_rank": S / (plain_ms["ms_per_step"] * 1e-3),
                 "sweep_frac": sweep_bytes / (plain_ms["phases_ms_per_step"]["backward"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "best_pick": {"collective": "one 16-byte ncclAllGather per iteration" if world > 1 else "none (one rank: device argmin only)",
+                          "last": {"cost": picks[-1][0], "global_instance": picks[-1][1]} if picks else None},
             "kernels_ms_per_step": {"bwd_contract": ms_a / steps,
                                     "bwd_riccati_and_gaps": (it.phase_ms["backward"] - ms_a) / steps, "fwd_rollout": ms_f / steps,
                                     "lin_first": ms_l1 / steps, "lin_second": ms_l2 / steps},
@@ -299,6 +311,12 @@ def main():
         extra = {}
         if world == 1 and not a.no_extra and S != 1:
             extra["config3_single_instance"] = single_instance_leg(capi, a, model, local_rank, T)
+            if full and a.fd_mode == 2:
+                for key, name in (("constrained_frame", "tree38_frame"), ("constrained_config", "tree38_config")):
+                    try:
+                        extra[key] = constrained_leg(capi, a, name, local_rank, T)
+                    except Exception as exc:            # a failure here must not cost the headline line
+                        extra[key] = {"error": repr(exc)}
         if extra:
             out["extra"] = extra
         if not a.no_cpu_baseline and a.cpu_iterations > 0:
@@ -306,8 +324,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()          # rank 0 may still be timing the CPU baseline: leave together
-        if shard is not None:
-            shard.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 
@@ -327,6 +345,104 @@ def single_instance_leg(capi, a, model, device, T):
     ctx.close()
     return {"workload": f"1 instance x {a.n_alpha} alphas, T={T}", "iterations_per_s": k / el, "ms_per_iteration": el / k * 1e3,
             "phases_ms": {p: v / k for p, v in it.phase_ms.items()}}
+
+
+def constrained_leg(capi, a, name, device, T, seeds=None, iters=2):
+    """One of the constrained problem classes at the bench size, on the headline's own kind of inputs (x0 neutral,
+    u ~ N(0, 0.1^2) per global seed): tree38_config -- test/pinocchio_ddp.cpp's shape, the neutral configuration asked for
+    at every step (e = 38) -- or tree38_frame -- config 5's shape, a 3-row frame-position constraint at T-2; two time
+    shifts, multipliers zero with N(0, 0.01^2)-seeded jacobians, mu = 1e3, reg = 0.
+    Every iteration is the reference's real one: update_derivatives (compute_derivatives, update_origin x 2, optimality,
+    multiplier update when its test passes: ddp.hpp:642-696) + backward_pass + forward_pass + swap (ddp.hpp:804-826).
+    Full DDP is tried first (mode-2 tensors of f and of the constraint chain in the sweep).  At T = 200 in double Q_uu does
+    not turn positive definite on any Talos-size constrained input tried (free rollouts, zero gravity, posture-holding
+    trajectories: tools/probe_constrained.py; the CPU restatement of the reference's algorithm agrees, and the reference
+    itself runs this shape in 500-digit mpfr: DESIGN.md 4d): then the tensors are still generated and timed, and the
+    iterations run tensor-free (Gauss-Newton sweeps: V != 0, K != 0, LLT restarts and step halvings happen)."""
+    from problems import make
+    S = seeds or a.seeds_per_gpu
+    model, spec, o = make(name, T, batch=S, fd_mode=2)
+    m, nx, n_, Etot = o.m, o.nx, o.n, o.Etot
+    us = np.stack([0.1 * np.random.default_rng(0xDD9000 + 5000 + g).normal(size=T * m) for g in range(S)])
+    jac = np.stack([0.01 * np.random.default_rng(0xDD9000 + 6000 + g).normal(size=Etot * n_) for g in range(S)])
+    state = {}
+
+    def load(ctx):
+        if "xs" not in state:
+            ctx.upload("X", np.zeros((S, (T + 1) * nx))); ctx.upload("U", us)
+            ctx.rollout()
+            state["xs"] = ctx.download("X")
+        xs = state["xs"]
+        ctx.upload("X", xs); ctx.upload("U", us); ctx.upload("X_NEW", xs); ctx.upload("U_NEW", us)
+        ctx.upload("MULT_ORIGIN", np.ascontiguousarray(xs[:, :T * nx]))
+        ctx.upload("MULT_VAL", np.zeros((S, Etot)))
+        ctx.upload("MULT_JAC", jac)
+
+    def iterate(ctx, max_restarts):
+        mu = np.full(S, 1e3); reg = np.zeros(S); w = np.full(S, 1e-1); n = np.full(S, 10.0)
+        ph = {"linearize": 0.0, "outer": 0.0, "backward": 0.0, "forward": 0.0}
+        steps_seen, restarts_seen = [], 0
+        ctx.linearize()                                      # ddp.hpp:768-772 ahead of the loop (also the warm-up)
+        _, _r, mu, _ = ctx.backward(reg, mu, max_restarts)
+        _, step, _ = ctx.forward(mu, n_alpha=a.n_alpha)
+        ctx.synchronize()
+        t_all = time.perf_counter()
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            ctx.linearize()
+            t1 = time.perf_counter()
+            ctx.update_origin(0); ctx.update_origin(1)
+            oo, cc = ctx.optimality(mu)
+            upd = (oo < w) & (cc < n)
+            if upd.any():
+                ctx.update_multipliers(np.where(upd, mu, 0.0))
+                oo2, _ = ctx.optimality(mu)
+                n = np.where(upd, oo2 / mu ** 0.1, n); w = np.where(upd, w / mu, w)
+            mu = np.where((oo < w) & ~(cc < n), mu * 10, mu)
+            t2 = time.perf_counter()
+            _, reg, mu, restarts = ctx.backward(reg, mu, max_restarts)
+            t3 = time.perf_counter()
+            _, step, dcost = ctx.forward(mu, n_alpha=a.n_alpha)
+            t4 = time.perf_counter()
+            reg = np.where(step >= 0.5, np.where(reg / 2 < 1e-5, 0.0, reg / 2), reg)
+            ctx.swap_traj()
+            ph["linearize"] += (t1 - t0) * 1e3; ph["outer"] += (t2 - t1) * 1e3
+            ph["backward"] += (t3 - t2) * 1e3; ph["forward"] += (t4 - t3) * 1e3
+            steps_seen += [float(x) for x in step]
+            restarts_seen += int(np.sum(restarts))
+        ctx.synchronize()
+        el = time.perf_counter() - t_all
+        return {"iterations_per_s": S * iters / el, "ms_per_iteration": el / iters * 1e3,
+                "phases_ms": {k: v / iters for k, v in ph.items()}, "paths": ctx.info(),
+                "accepted_steps": {"min": min(steps_seen), "median": float(np.median(steps_seen)), "max": max(steps_seen)},
+                "llt_restarts": restarts_seen, "max_abs_K_instance0": float(np.max(np.abs(ctx.download("FB_JAC", 0, 1))))}
+
+    out = {"workload": f"{name}: Talos-like tree, T={T}, {S} seeds x {a.n_alpha} alphas, "
+                       f"{'3-row frame constraint at T-2' if 'frame' in name else 'config constraint e=38 at every step'}, "
+                       "two time shifts, N(0,0.01^2) multiplier jacobians, mu=1e3"}
+    with capi.Context(spec, device=device) as ctx:
+        load(ctx)
+        try:
+            out["full_ddp"] = iterate(ctx, 8)
+        except capi.DdpHipError as exc:
+            if exc.code != capi.E_MAX_RESTARTS:
+                raise
+            load(ctx)
+            ctx.linearize(); ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.linearize(); ctx.synchronize()
+            out["full_ddp"] = {"sweep": "Q_uu not positive definite within 8 restarts at this horizon in double (as on the CPU restatement of "
+                                        "the reference's algorithm: DESIGN.md 4d); tensors generated and timed, the iterations below run tensor-free",
+                               "linearize_ms": (time.perf_counter() - t0) * 1e3, "paths": ctx.info()}
+    if "iterations_per_s" not in out["full_ddp"]:
+        _, spec0, _ = make(name, T, batch=S, fd_mode=0)
+        with capi.Context(spec0, device=device, flags=capi.FLAG_NO_TENSORS) as ctx:
+            load(ctx)
+            try:
+                out["tensor_free"] = iterate(ctx, 64)
+            except capi.DdpHipError as exc:
+                out["tensor_free"] = {"error": repr(exc)}
+    return out
 
 
 def pmc_traffic(S):

@@ -46,7 +46,8 @@ EXPORTS = [
     "ddp_hip_forward", "ddp_hip_cost_seq_aug", "ddp_hip_swap_traj",
     "ddp_hip_update_origin", "ddp_hip_optimality", "ddp_hip_update_multipliers", "ddp_hip_profile_enable",
     "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_comm_unique_id",
-    "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_builtin_model",
+    "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_shard_pick", "ddp_hip_shard_broadcast",
+    "ddp_hip_builtin_model",
     "ddp_hip_batch", "ddp_hip_set_active", "ddp_hip_solve", "ddp_hip_ctx_info",
     "ddp_hip_model_create", "ddp_hip_model_destroy", "ddp_hip_model_aba", "ddp_hip_model_aba_derivatives", "ddp_hip_model_frame",
 ]
@@ -146,6 +147,8 @@ def lib():
     L.ddp_hip_comm_init.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.ddp_hip_comm_destroy.argtypes = [C.c_void_p]
     L.ddp_hip_shard_best.argtypes = [C.c_void_p, C.c_double, C.c_int64, _dp, _lp]
+    L.ddp_hip_shard_pick.argtypes = [C.c_void_p, C.c_void_p, _dp, _lp]
+    L.ddp_hip_shard_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
     L.ddp_hip_builtin_model.argtypes = [C.c_int, C.c_uint64, C.POINTER(ModelStorage), C.POINTER(Model)]
     L.ddp_hip_batch.restype = C.c_int64
     L.ddp_hip_batch.argtypes = [C.c_void_p]
@@ -363,6 +366,19 @@ class Context:
     def swap_traj(self):
         _check(lib().ddp_hip_swap_traj(self._h), "swap_traj")
 
+    def shard_pick(self, comm=None):
+        """(best cost, global index) over every instance of every rank of `comm` (a Comm, or None: this context alone):
+        the cost of the trajectory `forward` just produced; one 16-byte all-gather (ddp_hip_shard_pick)"""
+        c, i = C.c_double(), C.c_int64()
+        _check(lib().ddp_hip_shard_pick(comm._h if comm is not None else None, self._h, C.byref(c), C.byref(i)), "shard_pick")
+        return c.value, i.value
+
+    def shard_broadcast(self, best_global_index, dst_local=0, comm=None):
+        """the winner's X, U, FB_* from its owner (rank = index mod G, local position index div G) into local instance
+        dst_local of every rank (ddp_hip_shard_broadcast)"""
+        _check(lib().ddp_hip_shard_broadcast(comm._h if comm is not None else None, self._h, int(best_global_index), int(dst_local)),
+               "shard_broadcast")
+
     def update_origin(self, which):
         _check(lib().ddp_hip_update_origin(self._h, which), "update_origin")
 
@@ -416,3 +432,36 @@ class Context:
 
     def bwd_algorithmic_bytes(self):
         return int(lib().ddp_hip_bwd_algorithmic_bytes(self._h))
+
+
+class Comm:
+    """The library's own RCCL communicator (csrc/comm.cpp).  `unique_id()` on rank 0, the 128 bytes travel to the other
+    ranks by whatever means the host has (bench.py: torch.distributed), then Comm(uid, rank, nranks, device) on every rank."""
+
+    @staticmethod
+    def unique_id():
+        uid = (C.c_ubyte * 128)()
+        _check(lib().ddp_hip_comm_unique_id(uid), "comm_unique_id")
+        return bytes(uid)
+
+    def __init__(self, uid, rank, nranks, device):
+        buf = (C.c_ubyte * 128)(*uid)
+        self._h = C.c_void_p()
+        _check(lib().ddp_hip_comm_init(buf, rank, nranks, device, C.byref(self._h)), "comm_init")
+        self.rank, self.nranks = rank, nranks
+
+    def best(self, cost, gidx):
+        c, i = C.c_double(), C.c_int64()
+        _check(lib().ddp_hip_shard_best(self._h, float(cost), int(gidx), C.byref(c), C.byref(i)), "shard_best")
+        return c.value, i.value
+
+    def close(self):
+        if self._h:
+            lib().ddp_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

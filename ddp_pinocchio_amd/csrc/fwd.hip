@@ -588,6 +588,7 @@ void fwd_teardown(ddp_hip_ctx* ctx) {
   if (ctx->fw_dcost) (void)hipFree(ctx->fw_dcost);
   if (ctx->step_d) (void)hipFree(ctx->step_d);
   if (ctx->fw_dcost_acc_d) (void)hipFree(ctx->fw_dcost_acc_d);
+  if (ctx->pick_pair_d) (void)hipFree(ctx->pick_pair_d);
   if (ctx->fw_state_d) (void)hipFree(ctx->fw_state_d);
 }
 

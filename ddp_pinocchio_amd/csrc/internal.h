@@ -115,6 +115,7 @@ struct ddp_hip_ctx {
   int32_t* fw_state_d = nullptr; // [batch] 0 searching, 1 accepted, 2 floor hit
   double* fw_dcost_acc_d = nullptr; // [batch]
   int32_t n_alpha_max = 8;
+  double* pick_pair_d = nullptr;  // best-cost pick of a single-rank run (comm.cpp: ddp_hip_shard_pick)
 
   // linearize workspace
   double* eq_ws = nullptr;     // constraint-chain workspace (large models)
@@ -159,5 +160,9 @@ bool fwd_lat_supported(const ddp_hip_ctx* ctx);   // the latency kernels of the 
 void fwd_teardown(ddp_hip_ctx* ctx);
 int lin_setup(ddp_hip_ctx* ctx);
 void lin_teardown(ddp_hip_ctx* ctx);
+
+// best-cost pick, device side (pick.hip): {cost, global index} of the local best / of G gathered pairs
+int pick_local_launch(ddp_hip_ctx* ctx, int64_t rank, int64_t nranks, double* out_pair, hipStream_t stream);
+int pick_final_launch(const double* pairs, int G, double* out_pair, hipStream_t stream);
 
 static inline int64_t seq_block_offset_regular(int64_t t, int64_t stride) { return t * stride; }

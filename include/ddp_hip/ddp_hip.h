@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DDP_HIP_ABI_VERSION 2
+#define DDP_HIP_ABI_VERSION 3
 
 enum {
   DDP_HIP_OK = 0,
@@ -248,6 +248,16 @@ int ddp_hip_comm_destroy(ddp_hip_comm* comm);
  * two 8-byte all-reduces over xGMI */
 int ddp_hip_shard_best(ddp_hip_comm* comm, double local_cost, int64_t local_global_index,
                        double* best_cost, int64_t* best_global_index);
+/* The pick on resident data, as ONE collective.  Ownership rule: global instance s lives on rank s mod G at local position
+ * s div G.  Every rank forms the cost of the trajectory ddp_hip_forward just produced for each of its instances
+ * (sum_t COSTS_OLD + the accepted step's cost difference), takes its local argmin on the device, one 16-byte ncclAllGather
+ * of {cost, global index} over xGMI, argmin of the G pairs on the device, one 16-byte read-back.  comm == NULL: a single
+ * rank (the same device work without the collective). */
+int ddp_hip_shard_pick(ddp_hip_comm* comm, ddp_hip_ctx* ctx, double* best_cost, int64_t* best_global_index);
+/* Optional: the winner's trajectory and gains (X, U, FB_ORIGIN, FB_VAL, FB_JAC of global instance best_global_index) from
+ * its owner into local instance dst_local of every rank: one grouped ncclBroadcast between the resident sequences
+ * (~4.9 MB at the Talos shape).  comm == NULL: a device copy. */
+int ddp_hip_shard_broadcast(ddp_hip_comm* comm, ddp_hip_ctx* ctx, int64_t best_global_index, int64_t dst_local);
 
 /* ---- the Model concept point by point (pinocchio_model.hpp:77-186), for a host-side model_t<double> (seam B2, see
  * adapters/pinocchio_double.cpp).  One configuration per call, evaluated on the device by the same rigid-body code the

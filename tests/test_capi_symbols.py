@@ -16,7 +16,7 @@ def test_library_loads_and_exports_header_symbols():
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(L, name), f"libddp_hip.so does not export {name}"
-    assert L.ddp_hip_abi_version() == 2
+    assert L.ddp_hip_abi_version() == 3
 
 
 def test_builtin_models_are_deterministic():

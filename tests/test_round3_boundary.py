@@ -1,0 +1,93 @@
+"""Round-3 additions at the boundary, on the device against the oracle:
+  * ddp_hip_forward with n_alpha = 0: forward_pass(do_linesearch = false), ddp_fwd.ipp:61-63;
+  * ddp_hip_shard_pick / ddp_hip_shard_broadcast: the best-cost pick as one collective on resident data and the winner's
+    broadcast (kernel map C1 / C2) over a one-rank RCCL communicator and with no communicator (the multi-rank
+    ownership / root logic is covered over gloo in tests/test_shard_gloo.py)."""
+import numpy as np
+import pytest
+
+from problems import initial_trajectory, make
+from synth import rel_err
+
+
+def _setup(capi, name, T, batch, seed, u_sigma, jac_sigma=0.0):
+    model, spec, o = make(name, T, batch=batch, fd_mode=0)
+    trajs = [initial_trajectory(o, model, seed=seed + b, u_sigma=u_sigma) for b in range(batch)]
+    ctx = capi.Context(spec, flags=capi.FLAG_NO_TENSORS)
+    rng = np.random.default_rng(seed)
+    mults = []
+    for b, (x0, us, xs) in enumerate(trajs):
+        ctx.upload("X", xs, b, 1); ctx.upload("U", us, b, 1); ctx.upload("X_NEW", xs, b, 1); ctx.upload("U_NEW", us, b, 1)
+        m = o.alloc_affine(o.Etot)
+        m["origin"][:] = xs[:T * o.nx]
+        if o.Etot:
+            m["jac"][:o.Etot * o.n] = jac_sigma * rng.normal(size=o.Etot * o.n)
+            for k, sname in (("origin", "MULT_ORIGIN"), ("val", "MULT_VAL"), ("jac", "MULT_JAC")):
+                ctx.upload(sname, m[k][:ctx.seq_size(sname)], b, 1)
+        mults.append(m)
+    return model, o, ctx, trajs, mults
+
+
+@pytest.mark.gpu
+def test_forward_without_linesearch_takes_the_full_step(gpu):
+    """do_linesearch == false (ddp_fwd.ipp:61-63): the rollout at step 1 is returned whatever the cost does.  The gains are
+    scaled up so that the full step INCREASES the cost (a line search would halve): X_NEW / U_NEW must still be the step-1
+    rollout of the oracle, and step_out 1."""
+    capi = gpu
+    T = 12
+    model, o, ctx, trajs, mults = _setup(capi, "chain6", T, 1, seed=5, u_sigma=0.05, jac_sigma=0.01)
+    with ctx:
+        x0, us, xs = trajs[0]
+        ctx.linearize()
+        rc, reg, mu, _ = ctx.backward(0.0, 100.0)
+        # blow the feed-forward term up: the full step overshoots
+        k = ctx.download("FB_VAL")[0]
+        ctx.upload("FB_VAL", 40.0 * k)
+        fb = {"origin": ctx.download("FB_ORIGIN")[0], "val": 40.0 * k, "jac": ctx.download("FB_JAC")[0]}
+        dc1, xs1, us1 = o.forward_alpha(1.0, xs, us, mults[0], fb, float(mu[0]))
+        assert dc1 > 0, "the test needs a full step that increases the cost"
+        rc, step, dcost = ctx.forward(mu, n_alpha=0)
+        assert step[0] == 1.0
+        assert rel_err(ctx.download("X_NEW")[0], xs1) < 1e-9 and rel_err(ctx.download("U_NEW")[0], us1) < 1e-9
+        assert abs(dcost[0] - dc1) <= 1e-9 * max(1.0, abs(dc1))
+        # with the line search the same inputs are halved
+        rc, step_ls, _ = ctx.forward(mu, n_alpha=8)
+        assert step_ls[0] < 1.0
+
+
+def _total_costs(ctx, dcost):
+    return ctx.download("COSTS_OLD").sum(axis=1) + dcost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_shard_pick_and_broadcast_single_rank(gpu, with_comm):
+    """the device-side pick (pick.hip) + the one-rank RCCL all-gather / grouped broadcast of csrc/comm.cpp"""
+    capi = gpu
+    T, B = 8, 5
+    # a constrained problem: V != 0, so the instances' costs differ (the unconstrained benchmark data give cost 0 for all)
+    model, o, ctx, trajs, mults = _setup(capi, "chain6", T, B, seed=31, u_sigma=0.05, jac_sigma=0.01)
+    comm = capi.Comm(capi.Comm.unique_id(), 0, 1, 0) if with_comm else None
+    try:
+        with ctx:
+            ctx.linearize()
+            rc, reg, mu, _ = ctx.backward(0.0, 100.0)
+            rc, step, dcost = ctx.forward(mu, n_alpha=8)
+            tot = _total_costs(ctx, dcost)
+            cost, idx = ctx.shard_pick(comm)
+            j = int(np.argmin(tot))
+            assert np.min(np.diff(np.sort(tot))) > 1e-9 * np.max(np.abs(tot)), "the test needs distinct costs"
+            assert idx == j and abs(cost - tot[j]) <= 1e-12 * max(1.0, abs(tot[j]))
+            # the winner's trajectory and gains into local instance 0 (dst != src unless the winner is 0)
+            ctx.swap_traj()
+            X, U, K = ctx.download("X"), ctx.download("U"), ctx.download("FB_JAC")
+            dst = (j + 1) % B
+            ctx.shard_broadcast(idx, dst_local=dst, comm=comm)
+            X2, U2, K2 = ctx.download("X"), ctx.download("U"), ctx.download("FB_JAC")
+            assert np.array_equal(X2[dst], X[j]) and np.array_equal(U2[dst], U[j]) and np.array_equal(K2[dst], K[j])
+            for b in range(B):
+                if b != dst:
+                    assert np.array_equal(X2[b], X[b]) and np.array_equal(K2[b], K[b])
+    finally:
+        if comm is not None:
+            comm.close()

@@ -48,3 +48,40 @@ def test_single_rank_needs_no_process_group():
     assert shard.best_of([3.0, 1.0, 2.0], [10, 11, 12]) == (1.0, 11)
     assert shard.instances_of_rank(5, 0, 1) == [0, 1, 2, 3, 4]
     assert shard.owner_of(7, 4) == 3
+
+
+def _worker_pick(rank, world, port, n_instances, ret):
+    import torch.distributed as dist
+    from ddp_pinocchio_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.instances_of_rank(n_instances, rank, world)
+    costs_all = np.array([(5 * g) % 13 + 0.5 for g in range(n_instances)])
+    costs_all[4] = costs_all[7] = -1.5                       # a tie across the two ranks: the smaller global index wins
+    best, idx = shard.pick(costs_all[mine], rank, world)
+    # the same answer as round 1's two all-reduces
+    best2, idx2 = shard.best_of(costs_all[mine], mine)
+    # the winner's "trajectory" to local row 0 of every rank: rows are labelled by their global index
+    X = np.stack([np.full(6, float(g)) for g in mine])
+    U = np.stack([np.full(3, 100.0 + g) for g in mine])
+    root, src = shard.broadcast_winner([X, U], idx, rank, world, dst_local=0)
+    ret[rank] = (best, idx, best2, idx2, root, src, X[0].tolist(), U[0].tolist(), X[1].tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_collective_pick_and_winner_broadcast_world2():
+    """ddp_hip_shard_pick / ddp_hip_shard_broadcast's ownership and root logic (instance s -> rank s mod G, local position
+    s div G) on the host mirror over gloo: the GPU box runs the library's RCCL path with the same rule"""
+    world, n = 2, 11
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_pick, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+        ret = dict(ret)
+    for r in range(world):
+        best, idx, best2, idx2, root, src, x0, u0, x1 = ret[r]
+        assert (best, idx) == (-1.5, 4) and (best2, idx2) == (-1.5, 4)
+        assert root == 0 and src == 2                            # global 4 lives on rank 0, third local instance
+        assert x0 == [4.0] * 6 and u0 == [104.0] * 3             # every rank now holds the winner in its row 0
+        assert x1 == [float(r + world)] * 6                      # the other rows are untouched
