@@ -713,7 +713,8 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
     // the Talos-like shape runs the split K3 / K4 kernels; every other shape (and DDP_HIP_GENERIC_BWD=1, kept for
     // cross-checking the two implementations against each other) the run-time-shaped pair
     const bool generic = getenv("DDP_HIP_GENERIC_BWD") != nullptr;
-    if (d.n == 76 && d.m == 38 && !generic) rc = getenv("DDP_HIP_BWD_V1") ? launch_sweep_split<76, 38>(ctx, p) : launch_sweep_v2<76, 38>(ctx, p);
+    // (K5 stages the multiplier jacobians over its V / F region: up to 52 constraint rows per step fit)
+    if (d.n == 76 && d.m == 38 && d.emax <= 52 && !generic) rc = getenv("DDP_HIP_BWD_V1") ? launch_sweep_split<76, 38>(ctx, p) : launch_sweep_v2<76, 38>(ctx, p);
     else if (d.n == 12 && d.m == 6) rc = launch_sweep<12, 6>(ctx, p, lds_a, lds_g);
     else rc = launch_sweep<0, 0>(ctx, p, lds_a, lds_g);
     if (rc != DDP_HIP_OK) return rc;

@@ -190,7 +190,14 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
   // D^T(c, j) = sum_k W(k, c) F(k, j): A(row = c, k) = W(k, c), B(k, col = j) = F(k, j); result (row = c = l4 + 4 q,
   // col = j = 16 jt + l15): consecutive lanes -> consecutive j, the fast index of every block of Q
   constexpr int JT = (NM + 15) / 16;
-  for (int tile = wave; tile < JT * CT; tile += NW) {
+  constexpr int TPW2 = (JT * CT + NW - 1) / NW;      // tiles per wave
+  double av_[TPW2][4];                               // l + D of this lane's entries, tile by tile
+#pragma unroll
+  for (int it_ = 0; it_ < TPW2; ++it_) {
+    const int tile = wave + it_ * NW;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av_[it_][q] = 0.0;
+    if (tile >= JT * CT) continue;
     const int jt = tile % JT, ct = tile / JT;
     const int cb = c0 + 16 * ct;                    // first column of this tile
     if (cb >= NM) continue;
@@ -217,46 +224,89 @@ __global__ __launch_bounds__(BS5) void bwd_dense2(BwdParams p, int64_t t) {
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
 #pragma unroll
+    for (int q = 0; q < 4; ++q) {                   // the reference's first two terms (ddp_bwd.ipp:70-71,77-78,83-84): l, f^T V_xx f
+      double a = lv[q];
+      a += acc[q];
+      av_[it_][q] = a;
+    }
+  }
+  // Multiplier terms (:72-73,:79,:85).  Round 2 formed them entry by entry from global memory (38 x 4 loads per entry of
+  // Q_xx at e = 38: 175 us per step against 56 without constraints).  Now eq_x, eq_u, pe_x and tmp2 = pe_x + mu eq_x are
+  // staged once in LDS over the dead V / F region (k fastest, k padded with zeros to a multiple of 4) and the products
+  //   eq_x^T tmp2, pe_x^T eq_x (Q_xx),  eq_u^T tmp2 (Q_ux),  eq_u^T eq_u (Q_uu)
+  // run on the FP64 matrix cores like the dense term.
+  const int LDE = (e + 3) & ~3;
+  double* s_EX = smem;                               // LDE x n
+  double* s_EU = s_EX + LDE * n;                     // LDE x m
+  double* s_PX = s_EU + LDE * m;                     // LDE x n
+  double* s_T2 = s_PX + LDE * n;                     // LDE x n
+  if (e > 0) {
+    lds_barrier();                                   // every wave is done with W and F
+    for (int idx = tid; idx < LDE * n; idx += BS5) {
+      const int k = idx % LDE, c = idx / LDE;
+      const double ex = k < e ? eqx[k + c * e] : 0.0, px = k < e ? pex[k + c * e] : 0.0;
+      s_EX[idx] = ex; s_PX[idx] = px; s_T2[idx] = k < e ? px + mu * ex : 0.0;        // :47
+    }
+    for (int idx = tid; idx < LDE * m; idx += BS5) {
+      const int k = idx % LDE, c = idx / LDE;
+      s_EU[idx] = k < e ? equ[k + c * e] : 0.0;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int it_ = 0; it_ < TPW2; ++it_) {
+    const int tile = wave + it_ * NW;
+    if (tile >= JT * CT) continue;
+    const int jt = tile % JT, ct = tile / JT;
+    const int cb = c0 + 16 * ct;
+    if (cb >= NM) continue;
+    if (cb >= n && 16 * jt + 15 < n) continue;
+    const int j = 16 * jt + l15;
+    const bool jok = j < NM;
+    f64x4 s1v = {0.0, 0.0, 0.0, 0.0}, s2v = {0.0, 0.0, 0.0, 0.0};
+    if (e > 0) {
+      // s1(j, c) = sum_k R(k, j) C(k, c), R = [eq_x | eq_u], C = tmp2 (x columns) / eq_u (u columns): A(row = c, k), B(k, col = j)
+      const int ca = cb + l15;                       // this lane's A column
+      const double* A1 = ca < n ? s_T2 + ca * LDE : s_EU + ((ca < NM ? ca : NM - 1) - n) * LDE;
+      const double* B1 = j < n ? s_EX + j * LDE : s_EU + ((jok ? j : NM - 1) - n) * LDE;
+      const double* A2 = s_EX + (ca < n ? ca : 0) * LDE;          // s2(j, c) = sum_k pe_x(k, j) eq_x(k, c): x-x entries only
+      const double* B2 = s_PX + (j < n ? j : 0) * LDE;
+      const bool aok = ca < NM, xx = cb < n && 16 * jt < n;       // the tile holds x-x entries (wave-uniform)
+      for (int ks = 0; ks < LDE; ks += 4) {
+        const double a1 = aok ? A1[ks + l4] : 0.0, b1 = jok ? B1[ks + l4] : 0.0;
+        s1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, s1v, 0, 0, 0);
+        if (xx) {
+          const double a2 = ca < n ? A2[ks + l4] : 0.0, b2 = j < n ? B2[ks + l4] : 0.0;
+          s2v = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, s2v, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = cb + l4 + 4 * q;                // column of Q (x column if < n, else u column)
       if (c >= NM || !jok) continue;
-      const double dval = acc[q];
       // entries of Q in the reference's order of terms (ddp_bwd.ipp:70-86): l, f^T V_xx f, multiplier terms, multiplier tensors
+      double a = av_[it_][q];
       if (c < n) {
         if (j < n) {                                // Q_xx(j, c)
-          double a = lv[q];
-          a += dval;
           if (e > 0) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = 0; k < e; ++k) {
-              s1 += eqx[k + j * e] * (pex[k + c * e] + mu * eqx[k + c * e]);          // :72
-              s2 += pex[k + j * e] * eqx[k + c * e];                                  // :73
-            }
-            a += s1;
-            a += s2;
+            a += s1v[q];                                                              // :72
+            a += s2v[q];                                                              // :73
             if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_xx[k + (j + c * n) * e]; a += s3; }   // :74
           }
           Pxx[j + c * n] = a;
         } else {                                    // Q_ux(j - n, c)
           const int i = j - n;
-          double a = lv[q];
-          a += dval;
           if (e > 0) {
-            double s1 = 0.0;
-            for (int k = 0; k < e; ++k) s1 += equ[k + i * e] * (pex[k + c * e] + mu * eqx[k + c * e]);   // :85
-            a += s1;
+            a += s1v[q];                                                              // :85
             if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_ux[k + (i + c * m) * e]; a += s3; }   // :86
           }
           Pux[i + c * m] = a;
         }
       } else if (j >= n) {                          // Q_uu(j - n, c - n)
         const int i = j - n, cu = c - n;
-        double a = lv[q];
-        a += dval;
         if (e > 0) {
-          double s1 = 0.0;
-          for (int k = 0; k < e; ++k) s1 += equ[k + i * e] * equ[k + cu * e];
-          a += s1 * mu;                                                               // :79
+          a += s1v[q] * mu;                                                           // :79
           if (tens) { double s3 = 0.0; for (int k = 0; k < e; ++k) s3 += s_tmp[k] * eq_uu[k + (i + cu * m) * e]; a += s3; }   // :80
         }
         Puu[i + cu * m] = a;

@@ -32,7 +32,9 @@ struct FwdParams {
   double* dcost_acc;
   int32_t* state;
   int32_t n_alpha, round;
-  int32_t no_linesearch, pad_;   // ddp_fwd.ipp:61-63: the full step is taken whatever the cost does
+  int32_t no_linesearch;         // ddp_fwd.ipp:61-63: the full step is taken whatever the cost does
+  int32_t cost_inline;           // latency kernel: 1 = forms sum_t (cost_new - cost_old) itself (no constraints), 0 = cand_cost_kernel does
+  double* fw_cost;               // [batch][n_alpha][T+1] cost terms of the candidates (constrained problems on the latency path)
 };
 
 // constraint value at solver time t: constraint_advance_time_t::eval_to (problem.hpp:563-567) applied
@@ -43,7 +45,8 @@ __device__ void eval_eq(const DevModel& m, const double* target, int e, const do
   double xa[2 * NJ + 1], xb[2 * NJ + 1];
   for (int i = 0; i < nx; ++i) xa[i] = x[i];
   for (int k = 0; k < m.eq_advance; ++k) {
-    rbd::eval_f<NJ>(m, xa, u, xb);
+    if (k + 1 < m.eq_advance) rbd::eval_f<NJ>(m, xa, u, xb);
+    else { for (int i = m.nq; i < nx; ++i) xb[i] = xa[i]; rbd::eval_f_q<NJ>(m, xa, xb); }   // the constraint reads q only (rbd.h: eval_f_q)
     for (int i = 0; i < nx; ++i) xa[i] = xb[i];
   }
   if (m.eq_kind == DDP_HIP_EQ_CONFIG) {
@@ -436,10 +439,10 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
     }
     rbd::coop_sync<true>();
     FSTAMP(fs, 0);
-    if (h == 0 && live) {
+    if (h == 0 && live && p.cost_inline) {
       double un = 0;
       for (int i = 0; i < nu; ++i) un += u[i] * u[i];
-      const double c_new = 0.5 * mc * un;                                       // problem_t::l (no constraints on this path)
+      const double c_new = 0.5 * mc * un;                                       // problem_t::l (constrained problems: cand_cost_kernel)
       dsum += c_new - cold_t;
     }
     }
@@ -467,10 +470,48 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   if (threadIdx.x == 0 && blockIdx.x == 0)
     for (int i = 0; i < 12; ++i) g_fwd_stamps[i] = fsv.acc[i];
 #endif
-  if (!OPEN && h == 0 && live && lead) {
+  if (!OPEN && h == 0 && live && lead && p.cost_inline) {
     dsum += 0.0 - cold[T];
     p.fw_dcost[(int64_t)b * na + a] = dsum;
   }
+}
+
+// Constrained problems on the latency path.  Only the rollout is sequential in t; the cost terms of a rolled-out candidate
+// (cost_seq_aug, ddp.hpp:699-735: l + pe . ce + mu/2 |ce|^2, with ce_t = eq(t, x_t, u_t) two look-ahead dynamics steps away,
+// problem.hpp:563-567) are independent across t: one lane per (instance, candidate, t) ...
+template <int NJ>
+__global__ void cand_cost_kernel(FwdParams p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t T = p.d.T;
+  const int na = p.n_alpha;
+  if (gid >= p.d.batch * na * T) return;
+  const int64_t t = gid % T;
+  const int a = (int)((gid / T) % na);
+  const int b = (int)(gid / (T * na));
+  if (p.state[b] != 0 || p.round * na + a > 33) return;
+  const DevModel& m = *p.model;
+  const int nx = m.nq + m.nv, nu = m.nv;
+  const double* xs = p.fw_x + (((int64_t)b * na + a) * (T + 1) + t) * nx;
+  const double* us = p.fw_u + (((int64_t)b * na + a) * T + t) * nu;
+  double x[2 * NJ + 1], u[NJ];
+  for (int i = 0; i < nx; ++i) x[i] = xs[i];
+  for (int i = 0; i < nu; ++i) u[i] = us[i];
+  p.fw_cost[((int64_t)b * na + a) * (T + 1) + t] = stage_cost<NJ>(p, m, b, t, x, u, p.mu[b]);
+}
+// ... and one lane per (instance, candidate) adds the differences up in the order of forward_kernel (ddp_fwd.ipp:54-56)
+__global__ void cand_sum_kernel(FwdParams p) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int na = p.n_alpha;
+  if (gid >= p.d.batch * na) return;
+  const int b = gid / na, a = gid % na;
+  if (p.state[b] != 0 || p.round * na + a > 33) return;
+  const int64_t T = p.d.T;
+  const double* cold = p.costs_old + (int64_t)b * (T + 1);
+  const double* cnew = p.fw_cost + ((int64_t)b * na + a) * (T + 1);
+  double dsum = 0.0;
+  for (int64_t t = 0; t < T; ++t) dsum += cnew[t] - cold[t];
+  dsum += 0.0 - cold[T];
+  p.fw_dcost[(int64_t)b * na + a] = dsum;
 }
 
 // accept rule (ddp_fwd.ipp:56-60): the first (= largest) candidate with sum(new - old) <= 0; the winner's
@@ -536,6 +577,8 @@ FwdParams make_params(ddp_hip_ctx* ctx) {
   p.fw_x = ctx->fw_x; p.fw_u = ctx->fw_u; p.fw_dcost = ctx->fw_dcost;
   p.step = ctx->step_d; p.dcost_acc = ctx->fw_dcost_acc_d; p.state = ctx->fw_state_d;
   p.n_alpha = ctx->n_alpha_max;
+  p.cost_inline = ctx->d.Etot == 0 ? 1 : 0;
+  p.fw_cost = ctx->fw_cost;
   p.round = 0;
   return p;
 }
@@ -552,7 +595,9 @@ FwdParams make_params(ddp_hip_ctx* ctx) {
 
 bool fwd_lat_supported(const ddp_hip_ctx* ctx) {
   const DevModel& m = ctx->model_h;
-  if (m.kind != DDP_HIP_MODEL_TREE || m.ff || ctx->d.Etot != 0 || ctx->d.nv != 38 || getenv("DDP_HIP_FWD_SCRATCH") != nullptr) return false;
+  // (constrained problems: the rollout runs on the latency kernel, the candidates' cost terms on cand_cost_kernel)
+  if (m.kind != DDP_HIP_MODEL_TREE || m.ff || ctx->d.nv != 38 || getenv("DDP_HIP_FWD_SCRATCH") != nullptr) return false;
+  if (ctx->d.Etot != 0 && getenv("DDP_HIP_FWD_EQ_SCRATCH") != nullptr) return false;   // development: round 2's one-lane-per-rollout kernel for constrained problems
   // the cooperative traversal: at most 8 joints per tree level (one helper lane each), 16 levels and 3 children per joint
   // (rbd::coop_role packs a lane's joint of a level into one word)
   if (m.max_level_width > 8 || m.n_levels > 16) return false;
@@ -567,6 +612,7 @@ int fwd_setup(ddp_hip_ctx* ctx) {
   HIP_TRY(hipMalloc(&ctx->fw_x, sizeof(double) * (size_t)(B * na * (d.T + 1) * d.nx)));
   HIP_TRY(hipMalloc(&ctx->fw_u, sizeof(double) * (size_t)(B * na * d.T * d.m)));
   HIP_TRY(hipMalloc(&ctx->fw_dcost, sizeof(double) * (size_t)(B * na)));
+  if (d.Etot > 0) HIP_TRY(hipMalloc(&ctx->fw_cost, sizeof(double) * (size_t)(B * na * (d.T + 1))));
   HIP_TRY(hipMalloc(&ctx->step_d, sizeof(double) * (size_t)B));
   HIP_TRY(hipMalloc(&ctx->fw_dcost_acc_d, sizeof(double) * (size_t)B));
   HIP_TRY(hipMalloc(&ctx->fw_state_d, sizeof(int32_t) * (size_t)B));
@@ -586,6 +632,7 @@ void fwd_teardown(ddp_hip_ctx* ctx) {
   if (ctx->fw_x) (void)hipFree(ctx->fw_x);
   if (ctx->fw_u) (void)hipFree(ctx->fw_u);
   if (ctx->fw_dcost) (void)hipFree(ctx->fw_dcost);
+  if (ctx->fw_cost) (void)hipFree(ctx->fw_cost);
   if (ctx->step_d) (void)hipFree(ctx->step_d);
   if (ctx->fw_dcost_acc_d) (void)hipFree(ctx->fw_dcost_acc_d);
   if (ctx->pick_pair_d) (void)hipFree(ctx->pick_pair_d);
@@ -662,10 +709,15 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
   for (int round = 0; round * n_alpha <= 33; ++round) {
     p.round = round;
     prof_begin(ctx, DDP_HIP_K_FWD_ROLLOUT);
-    // tree models without constraints: the latency path (one workgroup per instance, 8 lanes per candidate)
+    // tree models of the Talos size: the latency path (two workgroups per instance, 16 lanes per candidate); with constraints the
+    // cost terms of the rolled-out candidates come from cand_cost_kernel (parallel over t) instead of the rollout itself
     const bool lat_path = fwd_lat_supported(ctx) && n_alpha <= 8;
-    if (lat_path && getenv("DDP_HIP_FWD_LAT1") == nullptr) {
+    if (lat_path && (getenv("DDP_HIP_FWD_LAT1") == nullptr || !p.cost_inline)) {
       hipLaunchKernelGGL((forward_kernel_lat2<38>), dim3((unsigned)(2 * B)), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+      if (!p.cost_inline) {
+        hipLaunchKernelGGL((cand_cost_kernel<38>), dim3((unsigned)((B * n_alpha * d.T + 63) / 64)), dim3(64), 0, ctx->stream, p);
+        hipLaunchKernelGGL(cand_sum_kernel, dim3((unsigned)((B * n_alpha + 63) / 64)), dim3(64), 0, ctx->stream, p);
+      }
     } else if (lat_path) {
       const size_t lds = sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * 38 * 8 + 8 * (76 + 76 + 38 + 38));
       hipLaunchKernelGGL((forward_kernel_lat<38>), dim3((unsigned)B), dim3(64), lds, ctx->stream, p);

@@ -110,6 +110,7 @@ struct ddp_hip_ctx {
   double* fw_x = nullptr;      // [batch][n_alpha_max][(T+1)*nx]
   double* fw_u = nullptr;      // [batch][n_alpha_max][T*m]
   double* fw_dcost = nullptr;  // [batch][n_alpha_max]
+  double* fw_cost = nullptr;   // [batch][n_alpha_max][T+1] candidates' cost terms (constrained problems on the latency path)
   double* fw_cost_old = nullptr; // [batch]
   double* step_d = nullptr;    // [batch]
   int32_t* fw_state_d = nullptr; // [batch] 0 searching, 1 accepted, 2 floor hit

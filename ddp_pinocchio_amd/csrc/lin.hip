@@ -395,7 +395,8 @@ __device__ void eq_eval(const DevModel& m, const double* target, int e, const do
   double xa[2 * NJ + 1], xb[2 * NJ + 1];
   for (int i = 0; i < nx; ++i) xa[i] = x[i];
   for (int k = 0; k < m.eq_advance; ++k) {
-    rbd::eval_f<NJ>(m, xa, u, xb);
+    if (k + 1 < m.eq_advance) rbd::eval_f<NJ>(m, xa, u, xb);
+    else { for (int i = m.nq; i < nx; ++i) xb[i] = xa[i]; rbd::eval_f_q<NJ>(m, xa, xb); }   // the constraint reads q only: no dynamics in the last step
     for (int i = 0; i < nx; ++i) xa[i] = xb[i];
   }
   if (m.eq_kind == DDP_HIP_EQ_CONFIG) {
@@ -470,8 +471,9 @@ __global__ void eq_chain_kernel(LinParams p) {
   double xa[2 * NJ + 1], xb[2 * NJ + 1], u[NJ];
   load_xu<NJ>(p, b, t, xa, u);
   for (int k = 0; k < K; ++k) {                          // x_{k+1} = f(x_k, u): the SAME u at every look-ahead step
-    rbd::eval_f<NJ>(m, xa, u, xb);
-    for (int i = 0; i < nx; ++i) { xa[i] = xb[i]; p.eq_xk[(gid * K + k) * nx + i] = xb[i]; }
+    if (k + 1 < K || m.ff) rbd::eval_f<NJ>(m, xa, u, xb);   // (free flyer: eq_fdjac differences whole states on the group)
+    else { for (int i = m.nq; i < nx; ++i) xb[i] = xa[i]; rbd::eval_f_q<NJ>(m, xa, xb); }   // x_K: only its configuration is read (the constraint, and eq_fdjac's
+    for (int i = 0; i < nx; ++i) { xa[i] = xb[i]; p.eq_xk[(gid * K + k) * nx + i] = xb[i]; }  // q rows below) -- its velocity half is a placeholder
   }
   double* C = p.eq_c + gid * (int64_t)p.d.emax * n;
   for (int i = 0; i < e * n; ++i) C[i] = 0.0;
@@ -510,8 +512,18 @@ __global__ void eq_fdjac_kernel(LinParams p) {
   for (int i = 0; i < m.nv; ++i) u[i] = us[i];
   const double eps = sqrt(DBL_EPSILON);
   lie::perturb_x(m, x, j, eps);
-  rbd::eval_f<NJ>(m, x, u, f);
   double* col = p.eq_fxk + (bt * (K - 1) + k) * (int64_t)n * n + (int64_t)j * n;
+  if (k == K - 2 && !m.ff) {
+    // f_x(x_{K-1}) is multiplied from the left by the base jacobian C = [C_q | 0] (both constraint kinds read q only) and by
+    // nothing else: only its q rows matter, and those difference q+ = q + dt v -- no dynamics.  The very same values as the
+    // full column's q rows (the v rows, multiplied by exact zeros in eq_combine, are written as zeros): 76 forward-dynamics
+    // evaluations per constrained (instance, t) less.
+    const int nv = m.nv;
+    for (int i = 0; i < nv; ++i) { const double vo = m.dt * x[nv + i]; const double fq = x[i] + vo; col[i] = (fq - xk1[i]) / eps; }
+    for (int i = nv; i < n; ++i) col[i] = 0.0;
+    return;
+  }
+  rbd::eval_f<NJ>(m, x, u, f);
   if (m.ff) {
     double df[2 * NJ];
     lie::difference_x(m, xk1, f, df);

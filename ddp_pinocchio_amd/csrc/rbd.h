@@ -350,6 +350,25 @@ __device__ void eval_f(const DevModel& m, const double* x, const double* u, doub
   }
 }
 
+// The configuration half of eval_f alone: q+ = q (+) dt v, the very operations of eval_f (problem.hpp:450-452) without the
+// forward dynamics.  Both constraint kinds read q only (config_constraint_t problem.hpp:792-806, spatial_constraint_t
+// :679-689), so the LAST look-ahead step of a constraint chain (constraint_advance_time_t::eval_to, :563-567) does not need
+// its accelerations: bit-identical configurations at half the dynamics evaluations.  x_out's velocity half is left untouched.
+template <int NJ>
+__device__ __forceinline__ void eval_f_q(const DevModel& m, const double* x, double* x_out) {
+  const int nv = m.nv;
+  if (m.kind == DDP_HIP_MODEL_PENDULUM) { const double vo = m.dt * x[1]; x_out[0] = x[0] + vo; return; }
+  if (m.ff) {
+    const int nq = nv + 1;
+    double dq[6];
+    for (int k = 0; k < 6; ++k) dq[k] = m.dt * x[nq + k];
+    lie::se3_integrate(x, dq, x_out);
+    for (int i = 6; i < nv; ++i) { const double vo = m.dt * x[nq + i]; x_out[i + 1] = x[i + 1] + vo; }
+    return;
+  }
+  for (int i = 0; i < nv; ++i) { const double vo = m.dt * x[nv + i]; x_out[i] = x[i] + vo; }
+}
+
 // world position of a frame fixed at `off` in joint `joint`'s frame (pinocchio_model.ipp:418-430), and
 // optionally the reference's WORLD-frame jacobian rows (pinocchio_model.ipp:433-462): J is 3 x nv, ld 3
 template <int NJ>
