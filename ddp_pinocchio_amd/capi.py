@@ -216,6 +216,39 @@ class BuiltinModel:
         return q
 
 
+class TableModel(BuiltinModel):
+    """A tree of 1-DoF joints given as arrays (what adapters/urdf_reader.hpp produces from a URDF, or any robot description
+    the host has): parent[nv] (parent[i] < i, -1 = world), jtype[nv] (JOINT_REVOLUTE / JOINT_PRISMATIC), axis[nv][3] (unit,
+    joint frame), Rp[nv][3][3] and pp[nv][3] (placement in the parent frame), mass_j[nv], com[nv][3], Ic[nv][3][3] (about the
+    com).  Same attributes as BuiltinModel, so the product (ProblemSpec) and the oracle take it alike."""
+
+    def __init__(self, parent, jtype, axis, Rp, pp, mass_j, com, Ic, gravity=(0.0, 0.0, -9.81)):
+        nv = len(parent)
+        assert 1 <= nv <= 64
+        self.storage = ModelStorage()
+        self.model = Model()
+        st = self.storage
+        self.parent = np.ascontiguousarray(parent, dtype=np.int32)
+        self.jtype = np.ascontiguousarray(jtype, dtype=np.int32)
+        self.axis, self.Rp, self.pp = _f64(axis).reshape(nv, 3), _f64(Rp).reshape(nv, 3, 3), _f64(pp).reshape(nv, 3)
+        self.mass_j, self.com, self.Ic = _f64(mass_j).reshape(nv), _f64(com).reshape(nv, 3), _f64(Ic).reshape(nv, 3, 3)
+        for name, arr in (("parent", self.parent), ("jtype", self.jtype), ("axis", self.axis), ("Rp", self.Rp), ("pp", self.pp),
+                          ("mass_j", self.mass_j), ("com", self.com), ("Ic", self.Ic)):
+            dst = getattr(st, name)
+            flat = arr.reshape(-1)
+            for i in range(flat.size):
+                dst[i] = flat[i]
+        m = self.model
+        m.kind, m.nv, m.mass, m.length = MODEL_TREE, nv, 0.0, 0.0
+        m.parent = C.cast(st.parent, _ip); m.jtype = C.cast(st.jtype, _ip)
+        m.axis = C.cast(st.axis, _dp); m.Rp = C.cast(st.Rp, _dp); m.pp = C.cast(st.pp, _dp)
+        m.mass_j = C.cast(st.mass_j, _dp); m.com = C.cast(st.com, _dp); m.Ic = C.cast(st.Ic, _dp)
+        m.gravity = (C.c_double * 3)(*[float(g) for g in gravity])
+        self.kind, self.nv, self.mass, self.length = MODEL_TREE, nv, 0.0, 0.0
+        self.gravity = np.array([float(g) for g in gravity])
+        self.ff, self.nj, self.nq = False, nv, nv
+
+
 class ModelHandle:
     """Point evaluations of the Model concept on the device (ddp_hip_model_*, seam B2)"""
 

@@ -45,6 +45,10 @@ struct TopoChain6 {
   static constexpr int prismatic[N] = {0, 0, 0, 0, 0, 0};
 };
 
+}  // namespace
+#include "topo_extra.h"     // generated topologies (tools/gen_topology.py): struct Topo<Name> ..., DDP_TOPO_EXTRA(X)
+namespace {
+
 template <class T> constexpr bool has_child(int k) {
   for (int c = k + 1; c < T::N; ++c) if (T::parent[c] == k) return true;
   return false;
@@ -198,6 +202,13 @@ __device__ __forceinline__ unsigned int warm_block(const double* base, int lane)
 template <class T> constexpr bool parents_at_least(int from, int lo) {
   for (int k = from; k < T::N; ++k) if (T::parent[k] < lo) return false;
   return true;
+}
+// where the two-phase staging of a row's operands splits the joints: the largest KH <= N / 2 such that the joints above KH
+// only touch records KH .. N-1 (their own and their parents'); 19 for the Talos-like tree (its arms hang from joint 19),
+// 0 (no second phase) for a tree whose upper half reaches back to the root
+template <class T> constexpr int stage_split() {
+  for (int kh = T::N / 2; kh > 0; --kh) if (parents_at_least<T>(kh + 1, kh)) return kh;
+  return 0;
 }
 
 // Two-phase staging of a row's operands (E | r | U | 1/D from the q-cache block, the whole v-cache block): the records of the
@@ -522,8 +533,8 @@ __global__ __launch_bounds__(LBS, ROWS ? 1 : 3) void lin_static_tau_kernel(LinPa
   // scalar path its 76 per-joint reads are 76 serialised L2 round trips per wave (measured: 19.5 -> 17.6 ms at 64 seeds)
   unsigned int w = 0;
   double* s_V = s_P + nv * PS;
-  constexpr int KH = ROWS ? nv / 2 : 0;
-  StageRegs<nv, 0, ROWS ? KH : 1> lower;            // joints 0 .. KH-1: in flight through the first half of the leaf -> root pass
+  constexpr int KH = ROWS ? stage_split<T>() : 0;
+  StageRegs<nv, 0, (ROWS && KH > 0) ? KH : 1> lower;   // (KH == 0: joint 0 once more, harmless)            // joints 0 .. KH-1: in flight through the first half of the leaf -> root pass
   if constexpr (ROWS) {
     StageRegs<nv, KH, nv> upper;
     upper.load(qc, vc, lane);
@@ -601,6 +612,13 @@ template <class T> constexpr int n_children(int k) {
 template <class T> constexpr bool chain_start(int k) { return T::parent[k] < 0 || T::parent[k] != k - 1 || n_children<T>(T::parent[k]) > 1; }
 template <class T> constexpr bool chain_end(int k) { return k == T::N - 1 || chain_start<T>(k + 1); }
 template <class T> constexpr int chain_first(int k) { while (!chain_start<T>(k)) --k; return k; }
+// longest chain of the tree: sizes the LDS buffer of the chain-wise sweeps (8 for the Talos-like tree: its arms)
+template <class T> constexpr int max_chain() {
+  int best = 1;
+  for (int k = 0; k < T::N; ++k)
+    if (chain_end<T>(k)) { const int len = k - chain_first<T>(k) + 1; if (len > best) best = len; }
+  return best;
+}
 
 template <class T>
 struct VelState {
@@ -1121,7 +1139,7 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_up_kernel(LinParams p, con
                                                                 const double* __restrict__ xs, const double* __restrict__ us,
                                                                 double* __restrict__ ws, int64_t bt0) {
   constexpr int nv = T::N;
-  constexpr int MAXCH = 8;             // longest chain of the compiled-in topologies
+  constexpr int MAXCH = max_chain<T>();  // longest chain of the topology
   __shared__ double s_vel[MAXCH * 6 * LBS];
   CfgCtx c;
   int64_t bt;
@@ -1227,7 +1245,7 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
     vel_up_all<T>(c, s, std::make_integer_sequence<int, nv>{});
     vel_down_all<T>(c, s, std::make_integer_sequence<int, nv>{});
   } else {
-    constexpr int MAXCH = 8;
+    constexpr int MAXCH = max_chain<T>();
     __shared__ double s_vel[MAXCH * 6 * LBS];
     __shared__ double s_own[12 * LBS];
     if constexpr (!DIAG) {
@@ -1441,7 +1459,7 @@ __device__ __forceinline__ void qv_all(const QvCtx& c, QvState<T>& s, std::integ
 template <class T>
 __global__ __launch_bounds__(LBS, 2) void lin_static_qvcache_kernel(LinParams p, const DevModel* __restrict__ model, const double* __restrict__ xs,
                                                                  double* __restrict__ qcache, double* __restrict__ vcache) {
-  constexpr int nv = T::N, n = 2 * nv, MAXCH = 8;
+  constexpr int nv = T::N, n = 2 * nv, MAXCH = max_chain<T>();
   const int64_t bt = blockIdx.x;
   const int lane = threadIdx.x;
   const int64_t Tn = p.d.T;
@@ -1518,6 +1536,9 @@ int lin_static_supported(const DevModel& m) {
   if (m.ff) return 0;            // compiled-in topologies are trees of 1-DoF joints
   if (topo_matches<TopoTalos38>(m)) return 1;
   if (topo_matches<TopoChain6>(m)) return 2;
+#define DDP_TOPO_MATCH(ID, TOPO) if (topo_matches<TOPO>(m)) return (ID) - 1;   // generated topologies: lin_path ID, internal id ID - 1
+  DDP_TOPO_EXTRA(DDP_TOPO_MATCH)
+#undef DDP_TOPO_MATCH
   return 0;
 }
 
@@ -1582,5 +1603,8 @@ static int lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level) 
 int lin_static_launch(ddp_hip_ctx* ctx, const LinParams& p, int level) {
   if (ctx->lin_static == 1) return lin_static_launch_t<TopoTalos38>(ctx, p, level);
   if (ctx->lin_static == 2) return lin_static_launch_t<TopoChain6>(ctx, p, level);
+#define DDP_TOPO_LAUNCH(ID, TOPO) if (ctx->lin_static == (ID) - 1) return lin_static_launch_t<TOPO>(ctx, p, level);
+  DDP_TOPO_EXTRA(DDP_TOPO_LAUNCH)
+#undef DDP_TOPO_LAUNCH
   return DDP_HIP_E_UNSUPPORTED;
 }

@@ -1,0 +1,110 @@
+"""tools/gen_topology.py: static-topology stencil kernels for robots beyond the two written out in csrc/lin_static.hip
+("a build-time generator that emits a Topo* from a parent table so URDF-loaded models take the static
+path").  Two generated topologies ship compiled in -- a 7-joint serial arm and a 12-joint biped (a pelvis joint, two legs) --
+so that the generator's output is built and run on every round."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tools", "gen_topology.py")
+
+ARM7 = [-1, 0, 1, 2, 3, 4, 5]
+BIPED12 = [-1, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10]
+
+
+def test_generated_header_is_in_sync_and_lists_the_shipped_topologies():
+    out = subprocess.check_output([sys.executable, GEN, "--check"]).decode()
+    assert "in sync" in out
+    lst = subprocess.check_output([sys.executable, GEN, "--list"]).decode().split("\n")
+    assert any(l.startswith("4 Arm7 7 ") for l in lst) and any(l.startswith("5 Biped12 12 ") for l in lst)
+    hdr = open(os.path.join(ROOT, "ddp_pinocchio_amd", "csrc", "topo_extra.h")).read()
+    assert "X(4, TopoArm7)" in hdr and "X(5, TopoBiped12)" in hdr
+    src = open(os.path.join(ROOT, "ddp_pinocchio_amd", "csrc", "lin_static.hip")).read()
+    assert "DDP_TOPO_EXTRA(DDP_TOPO_MATCH)" in src and "DDP_TOPO_EXTRA(DDP_TOPO_LAUNCH)" in src
+
+
+def test_generator_reads_a_urdf(tmp_path):
+    """links / 1-DoF joints in file order, fixed joints merged into their parent (the reading of adapters/urdf_reader.hpp)"""
+    urdf = tmp_path / "arm.urdf"
+    urdf.write_text("""<robot name="r"><link name="base"/><link name="l1"/><link name="l2"/><link name="tool"/><link name="l3"/>
+      <joint name="j1" type="revolute"><parent link="base"/><child link="l1"/></joint>
+      <joint name="j2" type="prismatic"><parent link="l1"/><child link="l2"/></joint>
+      <joint name="jf" type="fixed"><parent link="l2"/><child link="tool"/></joint>
+      <joint name="j3" type="continuous"><parent link="tool"/><child link="l3"/></joint></robot>""")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_topology
+    parents, prismatic = gen_topology.from_urdf(str(urdf))
+    assert parents == [-1, 0, 1] and prismatic == [0, 1, 0]
+    text = gen_topology.render([{"name": "X3", "parents": parents, "prismatic": prismatic, "source": "arm.urdf"}])
+    assert "struct TopoX3" in text and "parent[N] = {-1, 0, 1}" in text and "X(4, TopoX3)" in text
+
+
+def seeded_tree(parents, seed):
+    """a random robot on a given tree: revolute joints, random axes / placements / inertias"""
+    from ddp_pinocchio_amd import capi
+    rng = np.random.default_rng(seed)
+    nv = len(parents)
+    axis = rng.normal(size=(nv, 3)); axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    Rp = np.stack([np.linalg.qr(rng.normal(size=(3, 3)))[0] for _ in range(nv)])
+    for k in range(nv):
+        if np.linalg.det(Rp[k]) < 0:
+            Rp[k][:, 0] = -Rp[k][:, 0]
+    pp = rng.uniform(0.05, 0.3, size=(nv, 3)) * rng.choice([-1.0, 1.0], size=(nv, 3))
+    mass = rng.uniform(0.5, 5.0, size=nv)
+    com = rng.uniform(-0.05, 0.05, size=(nv, 3))
+    Ic = np.zeros((nv, 3, 3))
+    for k in range(nv):
+        a = rng.uniform(0.05, 0.3, size=3)                  # a box with these half sizes
+        Ic[k] = np.diag(mass[k] / 3.0 * np.array([a[1] ** 2 + a[2] ** 2, a[0] ** 2 + a[2] ** 2, a[0] ** 2 + a[1] ** 2]))
+        Q = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        Ic[k] = Q @ Ic[k] @ Q.T
+    return capi.TableModel(parents, [capi.JOINT_REVOLUTE] * nv, axis, Rp, pp, mass, com, Ic)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parents,lin_path", [(ARM7, 4), (BIPED12, 5)])
+def test_generated_topology_takes_the_static_kernels_and_matches_the_oracle(gpu, parents, lin_path, monkeypatch):
+    capi = gpu
+    from oracle.binding import Oracle
+    from test_dynamics_parity import DERIV_SEQS, TENSOR_SEQS
+    model = seeded_tree(parents, seed=len(parents))
+    T, nv = 4, len(parents)
+    spec = capi.ProblemSpec(model, T, dt=0.01, c=1.0, batch=2, fd_mode=2, first_order_fd=1, eq_kind=capi.EQ_NONE,
+                            ne=np.zeros(T, dtype=np.int64))
+    o = Oracle(model, T, dt=0.01, c=1.0, fd_mode=2, first_order_fd=1, eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))
+    rng = np.random.default_rng(3)
+    trajs = []
+    for b in range(2):
+        us = 0.5 * rng.normal(size=T * nv)
+        x0 = np.concatenate([0.3 * rng.normal(size=nv), 0.2 * rng.normal(size=nv)])
+        trajs.append((us, o.rollout(x0, us)))
+
+    def run():
+        with capi.Context(spec) as ctx:
+            path = ctx.info()["lin_path"]
+            for b, (us, xs) in enumerate(trajs):
+                ctx.upload("X", xs, b, 1); ctx.upload("U", us, b, 1)
+            ctx.linearize()
+            return path, {k: ctx.download(s) for k, s in {**DERIV_SEQS, **TENSOR_SEQS}.items() if ctx.seq_size(s)}
+    path, got = run()
+    assert path == lin_path, "the model's tree matches a generated topology: the static kernels must take it"
+    monkeypatch.setenv("DDP_HIP_NO_STATIC", "1")
+    path_g, got_g = run()
+    monkeypatch.delenv("DDP_HIP_NO_STATIC")
+    assert path_g == 1
+    EPS, E1, E2 = 2.220446049250313e-16, 1.4901161193847656e-08, 1.220703125e-04
+    for b, (us, xs) in enumerate(trajs):
+        d = o.compute_derivatives(xs, us)
+        fscale = max(1.0, float(np.max(np.abs(d["f_val"]))))
+        tol1 = 8 * EPS * fscale / E1
+        tol2 = 64 * EPS * fscale / (E2 * E2) + 4 * tol1 / E2
+        for key in ("fx", "fu", "fxx", "fux", "fuu"):
+            ref = d[key][:got[key][b].size]
+            tol = (tol1 if key in ("fx", "fu") else tol2) * max(1.0, float(np.max(np.abs(ref))))
+            assert float(np.max(np.abs(got[key][b] - ref))) <= tol, (key, b)
+            # ... and so do the run-time-tree kernels (the A/B partner of the static path), i.e. the two agree within FD noise
+            assert float(np.max(np.abs(got_g[key][b] - ref))) <= tol, (key, b, "generic")
