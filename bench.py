@@ -262,6 +262,11 @@ def main():
         bytes_per_launch = 8.0 * words * S / launches_per_sweep if full else 0.0
         avg_s = (ms_a / max(n_a, 1)) * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        # bytes K3 physically reads: mode-2 / zero tensors are symmetric in their two input indices bit for bit, and K3 then
+        # reads one of each pair of mirrored f_xx half-slabs (m x n x m doubles per (instance, t) less: bwd_split.h, job kind 2).
+        # `achieved` stays SURVEY.md 8(d)'s algorithmic figure over the launch time; `read_gbs` is the physical stream
+        sym_skip = 8.0 * (m_ * n_ * m_) * S / launches_per_sweep if (full and a.fd_mode == 2 and not os.environ.get("DDP_HIP_K3_NO_SYM")) else 0.0
+        bytes_read = bytes_per_launch - sym_skip
         # the sweep-level figure SURVEY.md 8(d) / BASELINE.md 3 define: B_bwd of every resident instance / the time of the
         # whole backward phase (K3 + K4 + launch gaps + the status read-back)
         t_bwd = it.phase_ms["backward"] / steps * 1e-3
@@ -289,6 +294,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(S / launches_per_sweep),
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": n_a,
+                         "bytes_read_per_launch": bytes_read, "read_gbs": bytes_read / avg_s / 1e9 if avg_s > 0 else 0.0,
                          # whole backward phase: B_bwd x instances / t_backward (SURVEY.md 8d's definition)
                          "sweep_achieved": sweep_gbs, "sweep_frac": sweep_gbs / HBM_PEAK_GBS,
                          "sweep_bytes": sweep_bytes, "sweep_ms": t_bwd * 1e3},

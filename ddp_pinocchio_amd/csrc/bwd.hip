@@ -36,6 +36,8 @@ struct BwdParams {
   int32_t has_tensors;
   int32_t b0;          // first instance of the group this launch sweeps
   int32_t c_accumulate; // K3's epilogue adds its contraction to what is already in the Q workspace (bwd_v2.h) instead of storing it
+  int32_t sym_tensors;  // f_xx is symmetric in its two input indices bit for bit (mode-2 / zero tensors of this context's own linearisation):
+                        // K3 reads one of each pair of mirrored half-slabs (bwd_split.h, job kind 2)
 };
 
 constexpr int BS = 256;
@@ -400,7 +402,8 @@ BwdParams make_params(ddp_hip_ctx* ctx) {
   p.vx_trace = S(DDP_HIP_SEQ_VX_TRACE); p.vxx_trace = S(DDP_HIP_SEQ_VXX_TRACE);
   p.ws_V = ctx->ws_V; p.ws_Q = ctx->ws_Q; p.ws_D = ctx->ws_D; p.reg = ctx->reg_d; p.mu = ctx->mu_d;
   p.status = ctx->status_d; p.restarts = ctx->restarts_d;
-  p.jobs = ctx->jobs_d;
+  p.sym_tensors = (ctx->tensors_sym && ctx->jobs_sym_d && getenv("DDP_HIP_K3_NO_SYM") == nullptr) ? 1 : 0;
+  p.jobs = p.sym_tensors ? ctx->jobs_sym_d : ctx->jobs_d;
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
   return p;
 }
@@ -562,7 +565,7 @@ int launch_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   // profiled sweeps take the direct path: events recorded by a graph's event-record nodes cannot be read back with
   // hipEventElapsedTime on this ROCm (hipErrorInvalidHandle -- tried)
   if (!ctx->bwd_use_graph || (ctx->profile_mask & bwd_mask)) return enqueue_sweep_v2<NC, MC>(ctx, p0);
-  const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1);
+  const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1) | ((uint64_t)p0.sym_tensors << 2);
   auto find = [&](const void* key_x) -> ddp_hip_ctx::BwdGraph* {
     for (auto& g : ctx->bwd_graph)
       if (g.exec && g.key_x == key_x && g.key_misc == key_misc) return &g;
@@ -661,6 +664,13 @@ int bwd_setup(ddp_hip_ctx* ctx) {
   }
   HIP_TRY(hipMalloc(&ctx->jobs_d, sizeof(BwdJob) * jobs.size()));
   HIP_TRY(hipMemcpy(ctx->jobs_d, jobs.data(), sizeof(BwdJob) * jobs.size(), hipMemcpyHostToDevice));
+  if (n == 76 && m == 38 && cbx == 1) {
+    // the same list for symmetric tensors: the x-columns c >= m skip their first half-slab (job kind 2, bwd_split.h)
+    std::vector<BwdJob> js = jobs;
+    for (auto& j : js) if (j.kind == 0 && j.c0 >= m) j.kind = 2;
+    HIP_TRY(hipMalloc(&ctx->jobs_sym_d, sizeof(BwdJob) * js.size()));
+    HIP_TRY(hipMemcpy(ctx->jobs_sym_d, js.data(), sizeof(BwdJob) * js.size(), hipMemcpyHostToDevice));
+  }
   return DDP_HIP_OK;
 }
 
@@ -685,6 +695,7 @@ void bwd_teardown(ddp_hip_ctx* ctx) {
   if (ctx->status_d) (void)hipFree(ctx->status_d);
   if (ctx->restarts_d) (void)hipFree(ctx->restarts_d);
   if (ctx->jobs_d) (void)hipFree(ctx->jobs_d);
+  if (ctx->jobs_sym_d) (void)hipFree(ctx->jobs_sym_d);
 }
 
 extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io, int64_t* restarts_out, int64_t max_restarts) {

@@ -31,8 +31,13 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
   constexpr int n = N, m = M;
   const int64_t T = p.d.T;
   const int tid = threadIdx.x;
+  // kind 0: x-columns (f_xx in two half-slabs, f_ux), 1: u-columns (f_uu), 2: x-columns c >= M of SYMMETRIC tensors: the half-slab
+  // f_xx(:, 0:M, c) is not read -- its contraction C_xx(0:M, c) is the mirror image of C_xx(c, 0:M), which the jobs of the
+  // columns < M form from f_xx(:, M:N, 0:M) and write to both places.  Mode-2 tensors are symmetric bit for bit (the stencil
+  // writes one value to both entries, problem.hpp:283-292), so the mirrored sum is the very sum the skipped half would give
   const int kind = job.kind, c0 = job.c0, cn = job.cn;
-  const int rows = kind == 0 ? n + m : m;
+  const int rows = kind == 1 ? m : n + m;
+  static_assert(N == 2 * M, "half-slabs: the state tangent is twice the control dimension");
   const int64_t bt = (int64_t)b * T + t;
 
   const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
@@ -52,14 +57,15 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
   double* s_p1 = s_p0 + US::LD * M;
 
   // units: 76 x 38 column-major blocks; an x-column is f_xx(:,0:38,c), f_xx(:,38:76,c), f_ux(:,:,c); a u-column f_uu(:,:,c)
-  const int upc = kind == 0 ? 3 : 1;
+  const int upc = kind == 0 ? 3 : (kind == 2 ? 2 : 1);
+  const int part0 = kind == 2 ? 1 : 0;              // first part (row block of the column) this job reads
   const int U = upc * cn;
   const double* Txx = p.fxx + (bt * n + c0) * (int64_t)n * n;
   const double* Tux = p.fux + (bt * n + c0) * (int64_t)n * m;
   const double* Tuu = p.fuu + (bt * m + c0) * (int64_t)n * m;
   auto unit_ptr = [&](int u) -> const double* {
-    const int c = u / upc, part = u - c * upc;
-    if (kind == 0) return part < 2 ? Txx + (int64_t)c * n * n + part * (M * n) : Tux + (int64_t)c * n * m;
+    const int c = u / upc, part = u - c * upc + part0;
+    if (kind != 1) return part < 2 ? Txx + (int64_t)c * n * n + part * (M * n) : Tux + (int64_t)c * n * m;
     return Tuu + (int64_t)c * n * m;
   };
   f64x2 buf0[US::R], buf1[US::R], buf2[US::R], buf3[US::R];
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
         const double* pj = sp + tid * US::LD;                                               \
         double sacc = 0.0;                                                                  \
         _Pragma("unroll") for (int k = 0; k < US::HP; ++k) sacc += pj[k];                   \
-        const int c_ = (u) / upc, part_ = (u) - c_ * upc;                                   \
+        const int c_ = (u) / upc, part_ = (u) - c_ * upc + part0;                           \
         s_out[c_ * rows + part_ * M + tid] = sacc;                                          \
       }                                                                                     \
       C_ISSUE(BUF, (u) + 4);                                                                \
@@ -108,8 +114,13 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
     const int col = c0 + c;
     // c_accumulate: the workspace already holds every other term of Q (K5, bwd_v2.h); the tensor term comes last in the
     // reference as well (ddp_bwd.ipp:75,81,87)
-    double* dst = kind == 0 ? (r < n ? Cxx + r + col * n : Cux + (r - n) + col * m) : Cuu + r + col * m;
+    if (kind == 2 && r < M) continue;                // the mirror image: written by the job of column r
+    double* dst = kind != 1 ? (r < n ? Cxx + r + col * n : Cux + (r - n) + col * m) : Cuu + r + col * m;
     *dst = p.c_accumulate == 1 ? *dst + s_out[idx] : s_out[idx];
+    if (p.sym_tensors && kind == 0 && col < M && r >= M && r < n) {
+      double* dm = Cxx + col + r * n;                // C_xx(col, r) = C_xx(r, col): row col of column r >= M
+      *dm = p.c_accumulate == 1 ? *dm + s_out[idx] : s_out[idx];
+    }
   }
 }
 

@@ -348,6 +348,7 @@ extern "C" int64_t ddp_hip_seq_size(const ddp_hip_ctx* ctx, int seq) {
 
 extern "C" double* ddp_hip_device_ptr(ddp_hip_ctx* ctx, int seq) {
   if (!ctx || seq < 0 || seq >= DDP_HIP_SEQ_COUNT) return nullptr;
+  if (seq == DDP_HIP_SEQ_FXX) ctx->tensors_sym = false;   // the caller may write through the pointer: K3 reads every half-slab again
   return ctx->seq[seq].ptr;
 }
 
@@ -364,6 +365,7 @@ extern "C" int ddp_hip_upload(ddp_hip_ctx* ctx, int seq, const double* host, int
   int64_t sz = ctx->seq[seq].size;
   if (sz == 0 || count == 0) return DDP_HIP_OK;
   if (!host) return DDP_HIP_E_ARG;
+  if (seq == DDP_HIP_SEQ_FXX) ctx->tensors_sym = false;   // tensors from outside: no symmetry assumed (bwd_split.h, job kind 2)
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemcpyAsync(ctx->seq[seq].ptr + first * sz, host, sizeof(double) * (size_t)(sz * count), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -386,6 +388,7 @@ extern "C" int ddp_hip_fill(ddp_hip_ctx* ctx, int seq, double value) {
   int rc = check_range(ctx, seq, 0, 0);
   if (rc != DDP_HIP_OK) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
+  if (seq == DDP_HIP_SEQ_FXX) ctx->tensors_sym = false;
   return fill_device(ctx, ctx->seq[seq].ptr, ctx->seq[seq].size * ctx->d.batch, value);
 }
 

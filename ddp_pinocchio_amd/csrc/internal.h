@@ -89,6 +89,8 @@ struct ddp_hip_ctx {
   int32_t* status_d = nullptr; // [batch] 0 active, 1 failed this attempt, 2 done
   int64_t* restarts_d = nullptr;
   BwdJob* jobs_d = nullptr;
+  BwdJob* jobs_sym_d = nullptr;   // K3's job list for symmetric tensors (bwd_split.h, job kind 2)
+  bool tensors_sym = false;       // FXX / FUU hold what this context's own mode-2 (or tensor-free: zero) linearisation wrote: symmetric bit for bit
   int32_t njobs = 0;
   int32_t cbx = 0, cbu = 0;
   // the batch is swept in groups on their own streams: K3 of one group overlaps K4 of the others (bwd.hip)

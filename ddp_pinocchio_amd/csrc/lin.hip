@@ -968,6 +968,10 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   else rc = run_linearize<64>(ctx, p, stages);
   if (rc != DDP_HIP_OK) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // mode 2 writes one value to both (i, j, k) and (i, k, j) (problem.hpp:283-292), mode 0 leaves zeros: f_xx is symmetric bit
+  // for bit and the backward sweep reads one of each pair of mirrored half-slabs (bwd_split.h); mode 1's forward differences
+  // of jacobians are not
+  if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors) ctx->tensors_sym = ctx->model_h.fd_mode == 2 || ctx->model_h.fd_mode == 0;
   return DDP_HIP_OK;
 }
 

@@ -91,3 +91,40 @@ def test_shard_pick_and_broadcast_single_rank(gpu, with_comm):
     finally:
         if comm is not None:
             comm.close()
+
+
+@pytest.mark.gpu
+def test_backward_reads_one_of_each_mirrored_half_slab_bit_for_bit(gpu, monkeypatch):
+    """Mode-2 tensors are symmetric in their two input indices bit for bit (the stencil writes one value to both entries,
+    problem.hpp:283-292).  K3 then skips the half-slab f_xx(:, 0:m, c) of the columns c >= m and takes its contraction from
+    the mirror image (bwd_split.h, job kind 2): the sweep must give the very same gains and value function, bit for bit, as
+    with every half-slab read (DDP_HIP_K3_NO_SYM=1) -- and uploaded tensors (no symmetry known) take the full path."""
+    capi = gpu
+    T = 5
+    model, spec, o = make("tree38", T, batch=2, fd_mode=2)
+    with capi.Context(spec, flags=capi.FLAG_TRACE) as ctx:
+        for b in range(2):
+            x0, us, xs = initial_trajectory(o, model, seed=60 + b, u_sigma=0.4)
+            ctx.upload("X", xs, b, 1); ctx.upload("U", us, b, 1)
+        ctx.linearize()
+        # a V_x that is not zero: terminal cost gradient
+        ctx.upload("LFX", np.random.default_rng(1).normal(size=(2, o.n)))
+        ctx.upload("LFXX", np.tile(np.eye(o.n).reshape(-1), (2, 1)))
+        fxx = ctx.download("FXX")[0].reshape(T, o.n, o.n, o.n)                   # [t][k][j][i]
+        assert np.array_equal(fxx, fxx.transpose(0, 2, 1, 3)), "mode-2 f_xx is symmetric bit for bit"
+
+        def sweep():
+            rc, reg, mu, rs = ctx.backward(0.0, 1.0)
+            return ctx.download("FB_JAC"), ctx.download("FB_VAL"), ctx.download("VX_TRACE"), ctx.download("VXX_TRACE"), rs
+        sym = sweep()
+        monkeypatch.setenv("DDP_HIP_K3_NO_SYM", "1")
+        full = sweep()
+        monkeypatch.delenv("DDP_HIP_K3_NO_SYM")
+        for a_, b_ in zip(sym, full):
+            assert np.array_equal(a_, b_)
+        assert float(np.max(np.abs(sym[2]))) > 0
+        # tensors from outside: the flag drops (the same values here, so the answer is still the same)
+        ctx.upload("FXX", ctx.download("FXX"))
+        again = sweep()
+        for a_, b_ in zip(sym, again):
+            assert np.array_equal(a_, b_)
