@@ -705,6 +705,11 @@ extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io,
   HIP_TRY(hipSetDevice(ctx->device));
   BwdParams p = make_params(ctx);
   if (p.has_tensors && (!p.fxx || !p.fux || !p.fuu)) return DDP_HIP_E_UNSUPPORTED;
+  {
+    // the static stencil leaves the f_xx block out that the symmetric sweep never reads: any other sweep needs it
+    const bool fast = d.n == 76 && d.m == 38 && d.emax <= 52 && getenv("DDP_HIP_GENERIC_BWD") == nullptr;
+    if (p.has_tensors && ctx->fxx_mirror_pending && !(fast && p.sym_tensors)) { const int rc_ = lin_materialize_fxx(ctx); if (rc_ != DDP_HIP_OK) return rc_; }
+  }
 
   HIP_TRY(hipMemcpyAsync(ctx->reg_d, reg_io, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->mu_d, mu_io, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));

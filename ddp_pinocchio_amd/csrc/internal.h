@@ -90,6 +90,7 @@ struct ddp_hip_ctx {
   int64_t* restarts_d = nullptr;
   BwdJob* jobs_d = nullptr;
   BwdJob* jobs_sym_d = nullptr;   // K3's job list for symmetric tensors (bwd_split.h, job kind 2)
+  bool fxx_mirror_pending = false; // the static stencil left f_xx(:, q_i, v_c) out (lin.hip: lin_materialize_fxx forms it on demand)
   bool tensors_sym = false;       // FXX / FUU hold what this context's own mode-2 (or tensor-free: zero) linearisation wrote: symmetric bit for bit
   int32_t njobs = 0;
   int32_t cbx = 0, cbu = 0;
@@ -162,6 +163,7 @@ int fwd_setup(ddp_hip_ctx* ctx);
 bool fwd_lat_supported(const ddp_hip_ctx* ctx);   // the latency kernels of the forward sweep apply (tree, no constraints, Talos size)
 void fwd_teardown(ddp_hip_ctx* ctx);
 int lin_setup(ddp_hip_ctx* ctx);
+int lin_materialize_fxx(ddp_hip_ctx* ctx);   // FXX complete for readers outside the symmetric sweep (lin.hip)
 void lin_teardown(ddp_hip_ctx* ctx);
 
 // best-cost pick, device side (pick.hip): {cost, global index} of the local best / of G gathered pairs

@@ -732,6 +732,19 @@ __global__ void eq_second_m2_kernel(LinParams p, int stage) {
   }
 }
 
+// f_xx(:, q_i, v_c) = f_xx(:, v_c, q_i): the mirror image of the (q_i, v_c) block, which the static stencil leaves out while
+// the backward sweep is known to skip it (LinParams::skip_qv_mirror); formed when somebody else asks for FXX
+__global__ void fxx_qv_mirror_kernel(double* fxx, int64_t BT, int nv) {
+  const int n = 2 * nv;
+  const int64_t per = (int64_t)nv * nv * n, total = BT * per;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bt = g / per, r = g % per;
+    const int k = (int)(r % n), i = (int)((r / n) % nv), c = (int)(r / ((int64_t)n * nv));
+    double* T = fxx + bt * (int64_t)n * n * n;
+    T[k + (int64_t)i * n + (int64_t)(nv + c) * n * n] = T[k + (int64_t)(nv + c) * n + (int64_t)i * n * n];
+  }
+}
+
 LinParams make_params(ddp_hip_ctx* ctx) {
   LinParams p{};
   p.d = ctx->d;
@@ -748,6 +761,8 @@ LinParams make_params(ddp_hip_ctx* ctx) {
   p.eq_val = S(DDP_HIP_SEQ_EQ_VAL); p.eq_x = S(DDP_HIP_SEQ_EQ_X); p.eq_u = S(DDP_HIP_SEQ_EQ_U);
   p.eq_xx = S(DDP_HIP_SEQ_EQ_XX); p.eq_ux = S(DDP_HIP_SEQ_EQ_UX); p.eq_uu = S(DDP_HIP_SEQ_EQ_UU);
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
+  p.skip_qv_mirror = (ctx->jobs_sym_d && ctx->lin_static && ctx->model_h.fd_mode == 2 && getenv("DDP_HIP_K3_NO_SYM") == nullptr &&
+                      getenv("DDP_HIP_FXX_FULL") == nullptr) ? 1 : 0;
   p.eq_xk = ctx->eq_ws;
   if (p.eq_xk) {
     const Dims& dd = ctx->d;
@@ -971,7 +986,24 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   // mode 2 writes one value to both (i, j, k) and (i, k, j) (problem.hpp:283-292), mode 0 leaves zeros: f_xx is symmetric bit
   // for bit and the backward sweep reads one of each pair of mirrored half-slabs (bwd_split.h); mode 1's forward differences
   // of jacobians are not
-  if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors) ctx->tensors_sym = ctx->model_h.fd_mode == 2 || ctx->model_h.fd_mode == 0;
+  if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors) {
+    ctx->tensors_sym = ctx->model_h.fd_mode == 2 || ctx->model_h.fd_mode == 0;
+    ctx->fxx_mirror_pending = p.skip_qv_mirror != 0;
+  }
+  return DDP_HIP_OK;
+}
+
+// FXX complete for a reader that does not know about the skipped block (download, device_ptr, the run-time-shaped sweep)
+int lin_materialize_fxx(ddp_hip_ctx* ctx) {
+  if (!ctx->fxx_mirror_pending) return DDP_HIP_OK;
+  double* fxx = ctx->seq[DDP_HIP_SEQ_FXX].ptr;
+  if (fxx) {
+    const int64_t BT = ctx->d.batch * ctx->d.T;
+    hipLaunchKernelGGL(fxx_qv_mirror_kernel, dim3(4096), dim3(256), 0, ctx->stream, fxx, BT, (int)ctx->d.nv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->fxx_mirror_pending = false;
   return DDP_HIP_OK;
 }
 

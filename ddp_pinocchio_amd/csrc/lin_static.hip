@@ -872,7 +872,8 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
     for (int k = 0; k < nv; ++k) S.q[row * (nv + 1) + k] = s.uu[k];
     __syncthreads();
     // column (k, v_c) of slab q_i of f_xx: k + (nv + c) n + i n n; its mirror image: column q_i of slab v_c
-    rowblock_emit<nv, false>(S, lane, i, nv, fxx + (int64_t)nv * n + (int64_t)i * n * n, fxx + (int64_t)i * n + (int64_t)nv * n * n, (int64_t)n * n,
+    rowblock_emit<nv, false>(S, lane, i, nv, fxx + (int64_t)nv * n + (int64_t)i * n * n,
+                             kp->skip_qv_mirror ? nullptr : fxx + (int64_t)i * n + (int64_t)nv * n * n, (int64_t)n * n,
                              fxb + (int64_t)nv * n, fxx + (int64_t)nv * n + (int64_t)nv * n * n, (int64_t)n + (int64_t)n * n, dt,
                              kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
   } else {
