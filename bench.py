@@ -262,10 +262,11 @@ def main():
         bytes_per_launch = 8.0 * words * S / launches_per_sweep if full else 0.0
         avg_s = (ms_a / max(n_a, 1)) * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        # bytes K3 physically reads: mode-2 / zero tensors are symmetric in their two input indices bit for bit, and K3 then
-        # reads one of each pair of mirrored f_xx half-slabs (m x n x m doubles per (instance, t) less: bwd_split.h, job kind 2).
-        # `achieved` stays SURVEY.md 8(d)'s algorithmic figure over the launch time; `read_gbs` is the physical stream
-        sym_skip = 8.0 * (m_ * n_ * m_) * S / launches_per_sweep if (full and a.fd_mode == 2 and not os.environ.get("DDP_HIP_K3_NO_SYM")) else 0.0
+        # bytes K3 physically reads: mode-2 / zero tensors are symmetric in their two input indices bit for bit, and K3 then reads
+        # only the columns j >= c of slab c of f_xx and f_uu (n n (n-1)/2 + n m (m-1)/2 doubles per (instance, t) less:
+        # bwd_split.h).  `achieved` stays SURVEY.md 8(d)'s algorithmic figure over the launch time; `read_gbs` is the physical stream
+        sym_skip = (8.0 * (n_ * n_ * (n_ - 1) // 2 + n_ * m_ * (m_ - 1) // 2) * S / launches_per_sweep
+                    if (full and a.fd_mode == 2 and not os.environ.get("DDP_HIP_K3_NO_SYM")) else 0.0)
         bytes_read = bytes_per_launch - sym_skip
         # the sweep-level figure SURVEY.md 8(d) / BASELINE.md 3 define: B_bwd of every resident instance / the time of the
         # whole backward phase (K3 + K4 + launch gaps + the status read-back)

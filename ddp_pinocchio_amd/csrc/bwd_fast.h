@@ -30,3 +30,18 @@ __device__ __forceinline__ void slab_issue(const double* __restrict__ Tn, f64x2 
   }
 }
 
+
+// the same, for the columns jmin .. L-1 of the slab only (the others are not fetched; their buffer words are zero, so that the
+// reduction that follows leaves zeros for them): symmetric tensors, bwd_split.h
+template <int O, int L, bool NT>
+__device__ __forceinline__ void slab_issue_from(const double* __restrict__ Tn, f64x2 (&buf)[SlabShape<O, L>::R], int jmin) {
+  using S = SlabShape<O, L>;
+  const f64x2* __restrict__ T2 = reinterpret_cast<const f64x2*>(Tn);
+  const int fmin = jmin * S::HP;
+#pragma unroll
+  for (int r = 0; r < S::R; ++r) {
+    const int f = threadIdx.x + r * BSF;
+    if ((r < S::R - 1 || f < S::TOTAL) && f >= fmin) buf[r] = NT ? __builtin_nontemporal_load(&T2[f]) : T2[f];
+    else buf[r] = f64x2{0.0, 0.0};
+  }
+}

@@ -31,10 +31,12 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
   constexpr int n = N, m = M;
   const int64_t T = p.d.T;
   const int tid = threadIdx.x;
-  // kind 0: x-columns (f_xx in two half-slabs, f_ux), 1: u-columns (f_uu), 2: x-columns c >= M of SYMMETRIC tensors: the half-slab
-  // f_xx(:, 0:M, c) is not read -- its contraction C_xx(0:M, c) is the mirror image of C_xx(c, 0:M), which the jobs of the
-  // columns < M form from f_xx(:, M:N, 0:M) and write to both places.  Mode-2 tensors are symmetric bit for bit (the stencil
-  // writes one value to both entries, problem.hpp:283-292), so the mirrored sum is the very sum the skipped half would give
+  // kind 0: x-columns (f_xx in two half-slabs, f_ux), 1: u-columns (f_uu), 2: x-columns c >= M without their first half-slab.
+  // SYMMETRIC tensors (p.sym_tensors: this context's own mode-2 or zero tensors -- the stencil forms one value for the entries
+  // (i, j, c) and (i, c, j), problem.hpp:283-292): of slab c only the columns j >= c are read -- one contiguous tail of the slab
+  // -- and the contraction C(j, c) is written to (j, c) and to its mirror image (c, j); the entries j < c come from the jobs of
+  // the columns j.  The mirrored sum is the very sum the skipped column would have given, bit for bit.  Half of f_xx and of
+  // f_uu (2.16 of 6.31 MB per (instance, t)) is never read, and the stencil does not have to write it (lin_static.hip)
   const int kind = job.kind, c0 = job.c0, cn = job.cn;
   const int rows = kind == 1 ? m : n + m;
   static_assert(N == 2 * M, "half-slabs: the state tangent is twice the control dimension");
@@ -68,8 +70,17 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
     if (kind != 1) return part < 2 ? Txx + (int64_t)c * n * n + part * (M * n) : Tux + (int64_t)c * n * m;
     return Tuu + (int64_t)c * n * m;
   };
+  const bool sym = p.sym_tensors != 0;
+  auto unit_jmin = [&](int u) -> int {                 // first column of the unit that is read
+    if (!sym) return 0;
+    const int c = u / upc, part = u - c * upc + part0, col = c0 + c;
+    if (kind == 1) return col;                        // f_uu(:, j, col): j >= col
+    if (part == 0) return col < M ? col : M;          // f_xx(:, 0:M, col)
+    if (part == 1) return col > M ? col - M : 0;      // f_xx(:, M:N, col)
+    return 0;                                         // f_ux
+  };
   f64x2 buf0[US::R], buf1[US::R], buf2[US::R], buf3[US::R];
-#define C_ISSUE(BUF, u) do { if ((u) < U) slab_issue<N, M, BWD_NT>(unit_ptr(u), BUF); } while (0)
+#define C_ISSUE(BUF, u) do { if ((u) < U) slab_issue_from<N, M, BWD_NT>(unit_ptr(u), BUF, unit_jmin(u)); } while (0)
   C_ISSUE(buf0, 0); C_ISSUE(buf1, 1); C_ISSUE(buf2, 2); C_ISSUE(buf3, 3);
 
   for (int i = tid; i < n; i += BSF) s_v[i] = Vx[i];
@@ -114,11 +125,13 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
     const int col = c0 + c;
     // c_accumulate: the workspace already holds every other term of Q (K5, bwd_v2.h); the tensor term comes last in the
     // reference as well (ddp_bwd.ipp:75,81,87)
-    if (kind == 2 && r < M) continue;                // the mirror image: written by the job of column r
+    if (kind == 2 && r < M) continue;                // (the half-slab this job kind leaves out)
+    const bool square = kind == 1 || r < n;          // an entry of C_xx / C_uu (f_ux is not symmetric)
+    if (sym && square && r < col) continue;          // the mirror image: written by the job of column r
     double* dst = kind != 1 ? (r < n ? Cxx + r + col * n : Cux + (r - n) + col * m) : Cuu + r + col * m;
     *dst = p.c_accumulate == 1 ? *dst + s_out[idx] : s_out[idx];
-    if (p.sym_tensors && kind == 0 && col < M && r >= M && r < n) {
-      double* dm = Cxx + col + r * n;                // C_xx(col, r) = C_xx(r, col): row col of column r >= M
+    if (sym && square && r > col) {
+      double* dm = kind != 1 ? Cxx + col + r * n : Cuu + col + r * m;   // C(col, r) = C(r, col)
       *dm = p.c_accumulate == 1 ? *dm + s_out[idx] : s_out[idx];
     }
   }

@@ -348,7 +348,7 @@ extern "C" int64_t ddp_hip_seq_size(const ddp_hip_ctx* ctx, int seq) {
 
 extern "C" double* ddp_hip_device_ptr(ddp_hip_ctx* ctx, int seq) {
   if (!ctx || seq < 0 || seq >= DDP_HIP_SEQ_COUNT) return nullptr;
-  if (seq == DDP_HIP_SEQ_FXX) {
+  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUU) {
     (void)hipSetDevice(ctx->device);
     if (lin_materialize_fxx(ctx) != DDP_HIP_OK) return nullptr;
     ctx->tensors_sym = false;                              // the caller may write through the pointer: K3 reads every half-slab again
@@ -370,9 +370,8 @@ extern "C" int ddp_hip_upload(ddp_hip_ctx* ctx, int seq, const double* host, int
   if (sz == 0 || count == 0) return DDP_HIP_OK;
   if (!host) return DDP_HIP_E_ARG;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (seq == DDP_HIP_SEQ_FXX) {                           // tensors from outside: no symmetry assumed (bwd_split.h, job kind 2)
-    if (count < ctx->d.batch) { const int rc_ = lin_materialize_fxx(ctx); if (rc_ != DDP_HIP_OK) return rc_; }   // the other instances keep theirs
-    ctx->fxx_mirror_pending = false;
+  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUU) {   // tensors from outside: no symmetry assumed (bwd_split.h)
+    { const int rc_ = lin_materialize_fxx(ctx); if (rc_ != DDP_HIP_OK) return rc_; }   // what is not overwritten (other instances, the other tensor) stays whole
     ctx->tensors_sym = false;
   }
   HIP_TRY(hipMemcpyAsync(ctx->seq[seq].ptr + first * sz, host, sizeof(double) * (size_t)(sz * count), hipMemcpyHostToDevice, ctx->stream));
@@ -387,7 +386,7 @@ extern "C" int ddp_hip_download(ddp_hip_ctx* ctx, int seq, double* host, int64_t
   if (sz == 0 || count == 0) return DDP_HIP_OK;
   if (!host) return DDP_HIP_E_ARG;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (seq == DDP_HIP_SEQ_FXX) { const int rc_ = lin_materialize_fxx(ctx); if (rc_ != DDP_HIP_OK) return rc_; }
+  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUU) { const int rc_ = lin_materialize_fxx(ctx); if (rc_ != DDP_HIP_OK) return rc_; }
   HIP_TRY(hipMemcpyAsync(host, ctx->seq[seq].ptr + first * sz, sizeof(double) * (size_t)(sz * count), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return DDP_HIP_OK;
@@ -397,7 +396,11 @@ extern "C" int ddp_hip_fill(ddp_hip_ctx* ctx, int seq, double value) {
   int rc = check_range(ctx, seq, 0, 0);
   if (rc != DDP_HIP_OK) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (seq == DDP_HIP_SEQ_FXX) { ctx->tensors_sym = false; ctx->fxx_mirror_pending = false; }
+  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUU) {
+    const int rc_ = lin_materialize_fxx(ctx);
+    if (rc_ != DDP_HIP_OK) return rc_;
+    ctx->tensors_sym = false;
+  }
   return fill_device(ctx, ctx->seq[seq].ptr, ctx->seq[seq].size * ctx->d.batch, value);
 }
 

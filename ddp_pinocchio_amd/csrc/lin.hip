@@ -732,16 +732,17 @@ __global__ void eq_second_m2_kernel(LinParams p, int stage) {
   }
 }
 
-// f_xx(:, q_i, v_c) = f_xx(:, v_c, q_i): the mirror image of the (q_i, v_c) block, which the static stencil leaves out while
-// the backward sweep is known to skip it (LinParams::skip_qv_mirror); formed when somebody else asks for FXX
-__global__ void fxx_qv_mirror_kernel(double* fxx, int64_t BT, int nv) {
-  const int n = 2 * nv;
-  const int64_t per = (int64_t)nv * nv * n, total = BT * per;
+// T(:, i, j) = T(:, j, i) for i < j: the mirror images of a symmetric tensor's entries (f_xx: L = n; f_uu: L = m), which the
+// static stencil leaves out while the backward sweep is known not to read them (LinParams::skip_qv_mirror); formed when
+// somebody else asks for FXX / FUU
+__global__ void tensor_mirror_kernel(double* Tn, int64_t BT, int n, int L) {
+  const int64_t per = (int64_t)n * L * L, total = BT * per;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t bt = g / per, r = g % per;
-    const int k = (int)(r % n), i = (int)((r / n) % nv), c = (int)(r / ((int64_t)n * nv));
-    double* T = fxx + bt * (int64_t)n * n * n;
-    T[k + (int64_t)i * n + (int64_t)(nv + c) * n * n] = T[k + (int64_t)(nv + c) * n + (int64_t)i * n * n];
+    const int k = (int)(r % n), j = (int)((r / n) % L), c = (int)(r / ((int64_t)n * L));   // entry (k, j, c): column j of slab c
+    if (j >= c) continue;
+    double* T = Tn + bt * per;
+    T[k + (int64_t)j * n + (int64_t)c * n * L] = T[k + (int64_t)c * n + (int64_t)j * n * L];   // its direct twin: column c of slab j
   }
 }
 
@@ -997,9 +998,11 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
 int lin_materialize_fxx(ddp_hip_ctx* ctx) {
   if (!ctx->fxx_mirror_pending) return DDP_HIP_OK;
   double* fxx = ctx->seq[DDP_HIP_SEQ_FXX].ptr;
-  if (fxx) {
+  double* fuu = ctx->seq[DDP_HIP_SEQ_FUU].ptr;
+  if (fxx && fuu) {
     const int64_t BT = ctx->d.batch * ctx->d.T;
-    hipLaunchKernelGGL(fxx_qv_mirror_kernel, dim3(4096), dim3(256), 0, ctx->stream, fxx, BT, (int)ctx->d.nv);
+    hipLaunchKernelGGL(tensor_mirror_kernel, dim3(8192), dim3(256), 0, ctx->stream, fxx, BT, (int)ctx->d.n, (int)ctx->d.n);
+    hipLaunchKernelGGL(tensor_mirror_kernel, dim3(4096), dim3(256), 0, ctx->stream, fuu, BT, (int)ctx->d.n, (int)ctx->d.m);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }

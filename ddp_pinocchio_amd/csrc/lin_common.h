@@ -16,8 +16,9 @@ struct LinParams {
   double *eq_xk, *eq_fxk, *eq_c;   // large-model constraint chain workspace: x_1..x_K | f_x(x_1..x_{K-1}) | base jacobian
   double* vcache;   // [batch*T][2nv+1][nv*VC_STRIDE]: (q, v)-dependent part at (q,v), (q, v+eps e_i), (q+eps e_i, v)
   double* qcache;   // [batch*T][nv+1][nv*QC_STRIDE]: q-dependent part of the ABA at the base q and at q + eps e_i (mode 2)
-  int32_t skip_qv_mirror;   // static stencil: do not write f_xx(:, q_i, v_c) -- the mirror image of the (q_i, v_c) entries, which the
-                            // backward sweep never reads when it knows the tensors symmetric (bwd_split.h); formed on demand (lin.hip)
+  int32_t skip_qv_mirror;   // static stencil: do not write the mirror images f_xx(:, i, j), f_uu(:, i, j), i < j, of the symmetric pairs --
+                            // the backward sweep never reads them when it knows the tensors symmetric (bwd_split.h: only the columns
+                            // j >= c of slab c); formed on demand for any other reader (lin.hip: lin_materialize_fxx)
   int32_t ncfg, nvcfg;   // entries per (instance, t) of the q- / v-cache: nv+1 / 2nv+1 with the mode-2 stencil resident,
                          // 1 / 1 when only the first order is formed (tensor-free contexts: base configuration and base (q, v))
 };

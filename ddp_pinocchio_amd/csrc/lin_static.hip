@@ -330,7 +330,7 @@ __device__ __forceinline__ void offdiag_emit(const LinParams& p, OutStage<NV, NP
       if (at_x_1) { if (at_x_2) { tensor = fxx; L = n; } else { tensor = fux; L = mm; } }
       else { tensor = fuu; L = mm; }
       o0[u] = (pk >> 16) ? tensor + (int64_t)idx_2 * n + (int64_t)idx_1 * n * L : nullptr;
-      o1[u] = ((pk >> 16) && at_x_1 == at_x_2) ? tensor + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L : nullptr;
+      o1[u] = ((pk >> 16) && at_x_1 == at_x_2 && !p.skip_qv_mirror) ? tensor + (int64_t)idx_1 * n + (int64_t)idx_2 * n * L : nullptr;
       if (o0[u]) {
         const double* q0 = at_x_1 ? fxb + (int64_t)idx_1 * n : fub + (int64_t)idx_1 * n;
         const double* q1 = at_x_2 ? fxb + (int64_t)idx_2 * n : fub + (int64_t)idx_2 * n;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(LBS, ROWS ? 1 : 3) void lin_static_tau_kernel(LinPa
   } else {
     __shared__ OutStage<nv, LBS / 2> S;
     LinParams po;
-    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
+    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror;
     const double dt = m.dt;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
                              kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
   } else {
     LinParams po;
-    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
+    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror;
     offdiag_emit<nv, LBS>(po, S, valid, i, j, bt, c.xg, dt);
   }
 }
@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, c
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   LinParams po;
-  po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu;
+  po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror;
   offdiag_emit<nv, LBS>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
 }
 
