@@ -275,7 +275,8 @@ def main():
         sweep_gbs = sweep_bytes / t_bwd / 1e9 if t_bwd > 0 else 0.0
         lin2_s = ms_l2 / steps * 1e-3
         lin2_flops = stencil_flops_per_bt(nv, a.fd_mode if full else 0) * S * T
-        lin2_bytes = 8.0 * (n_ ** 3 + n_ * n_ * m_ + n_ * m_ * m_) * S * T if full else 0.0
+        # tensor bytes the stencil writes: all of them, less the mirror images the symmetric sweep never reads (formed on demand)
+        lin2_bytes = (8.0 * (n_ ** 3 + n_ * n_ * m_ + n_ * m_ * m_) * S * T - sym_skip * launches_per_sweep * T) if full else 0.0
         out = {
             "metric": "DDP iterations/sec (fwd+bwd sweep), Talos nq=38 T=200",
             "value": total * a.steps / elapsed,

@@ -91,6 +91,7 @@ struct ddp_hip_ctx {
   BwdJob* jobs_d = nullptr;
   BwdJob* jobs_sym_d = nullptr;   // K3's job list for symmetric tensors (bwd_split.h, job kind 2)
   bool fxx_mirror_pending = false; // the static stencil left f_xx(:, q_i, v_c) out (lin.hip: lin_materialize_fxx forms it on demand)
+  bool tensor_tops_zero = false;   // rows k < nv of every column of FXX / FUX / FUU hold zeros (what LinParams::skip_top relies on)
   bool tensors_sym = false;       // FXX / FUU hold what this context's own mode-2 (or tensor-free: zero) linearisation wrote: symmetric bit for bit
   int32_t njobs = 0;
   int32_t cbx = 0, cbu = 0;

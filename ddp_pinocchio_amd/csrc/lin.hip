@@ -746,6 +746,16 @@ __global__ void tensor_mirror_kernel(double* Tn, int64_t BT, int n, int L) {
   }
 }
 
+// rows k < nv of every column of a tensor (O = n rows, `cols` columns per (instance, t)) to zero: what the static stencil
+// relies on when it skips them (LinParams::skip_top)
+__global__ void tensor_zero_top_kernel(double* Tn, int64_t total_cols, int n, int nv) {
+  const int64_t total = total_cols * nv;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = g / nv;
+    Tn[col * n + (g % nv)] = 0.0;
+  }
+}
+
 LinParams make_params(ddp_hip_ctx* ctx) {
   LinParams p{};
   p.d = ctx->d;
@@ -762,6 +772,7 @@ LinParams make_params(ddp_hip_ctx* ctx) {
   p.eq_val = S(DDP_HIP_SEQ_EQ_VAL); p.eq_x = S(DDP_HIP_SEQ_EQ_X); p.eq_u = S(DDP_HIP_SEQ_EQ_U);
   p.eq_xx = S(DDP_HIP_SEQ_EQ_XX); p.eq_ux = S(DDP_HIP_SEQ_EQ_UX); p.eq_uu = S(DDP_HIP_SEQ_EQ_UU);
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
+  p.skip_top = (ctx->lin_static && ctx->model_h.fd_mode == 2 && !ctx->model_h.ff && getenv("DDP_HIP_FXX_FULL") == nullptr) ? 1 : 0;
   p.skip_qv_mirror = (ctx->jobs_sym_d && ctx->lin_static && ctx->model_h.fd_mode == 2 && getenv("DDP_HIP_K3_NO_SYM") == nullptr &&
                       getenv("DDP_HIP_FXX_FULL") == nullptr) ? 1 : 0;
   p.eq_xk = ctx->eq_ws;
@@ -978,6 +989,16 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   LinParams p = make_params(ctx);
   int rc;
   const int nv = (int)ctx->d.nv;
+  if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors && p.skip_top && !ctx->tensor_tops_zero) {
+    // the configuration rows the static stencil leaves alone must hold zeros: once per context, and again after somebody
+    // else has written to the tensors (upload / fill / device_ptr)
+    const int64_t BT = ctx->d.batch * ctx->d.T, n = ctx->d.n, m = ctx->d.m;
+    hipLaunchKernelGGL(tensor_zero_top_kernel, dim3(8192), dim3(256), 0, ctx->stream, p.fxx, BT * n * n, (int)n, nv);
+    hipLaunchKernelGGL(tensor_zero_top_kernel, dim3(8192), dim3(256), 0, ctx->stream, p.fux, BT * m * n, (int)n, nv);
+    hipLaunchKernelGGL(tensor_zero_top_kernel, dim3(8192), dim3(256), 0, ctx->stream, p.fuu, BT * m * m, (int)n, nv);
+    HIP_TRY(hipGetLastError());
+    ctx->tensor_tops_zero = true;
+  }
   if (nv <= 1) rc = run_linearize<1>(ctx, p, stages);
   else if (nv <= 6 && !ctx->model_h.ff) rc = run_linearize<6>(ctx, p, stages);   // (the one-lane constraint chain of small models is vector-space only)
   else if (nv <= 38) rc = run_linearize<38>(ctx, p, stages);

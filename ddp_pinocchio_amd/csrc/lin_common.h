@@ -19,6 +19,10 @@ struct LinParams {
   int32_t skip_qv_mirror;   // static stencil: do not write the mirror images f_xx(:, i, j), f_uu(:, i, j), i < j, of the symmetric pairs --
                             // the backward sweep never reads them when it knows the tensors symmetric (bwd_split.h: only the columns
                             // j >= c of slab c); formed on demand for any other reader (lin.hip: lin_materialize_fxx)
+  int32_t skip_top;         // static stencil: the configuration rows k < nv of a tensor column are exact zeros except at k = (first
+                            // direction) mod nv and k = (second direction) mod nv -- q+ = q + dt v is affine, and row k of every stencil
+                            // point but those two is bit for bit the base point's -- so only those two and the rows k >= nv are formed
+                            // and stored; the other rows hold the zeros lin.hip: tensor_zero_top_kernel left there
   int32_t ncfg, nvcfg;   // entries per (instance, t) of the q- / v-cache: nv+1 / 2nv+1 with the mode-2 stencil resident,
                          // 1 / 1 when only the first order is formed (tensor-free contexts: base configuration and base (q, v))
 };

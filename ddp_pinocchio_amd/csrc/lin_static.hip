@@ -351,6 +351,9 @@ __device__ __forceinline__ void offdiag_emit(const LinParams& p, OutStage<NV, NP
       for (int jx = 0; jx < NJ; ++jx) {
         const int k = kk + RW * jx;
         if (k >= n) continue;
+        // configuration rows: q+ = q + dt v does not see the dynamics; row k < nv of a stencil point differs from the base point's
+        // only when one of the two directions is q_k or v_k -- every other entry is an exact zero, already in memory (skip_top)
+        if (p.skip_top && k < NV && !((ie[u] < n && ie[u] % NV == k) || (je[u] < n && je[u] % NV == k))) continue;
         // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
         double xs = k == ie[u] ? xk[jx] + eps : xk[jx];
         if (k == je[u]) xs = xs + eps;
@@ -400,8 +403,9 @@ template <int NV, bool DIAG_ROW, class ST>
 __device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int jb, double* __restrict__ out, double* __restrict__ mirror,
                                               int64_t mstride, const double* __restrict__ a2, const double* __restrict__ d2, int64_t dstride,
                                               double dt, const double* __restrict__ f0g, const double* __restrict__ a1g,
-                                              double* __restrict__ d1g, const double* __restrict__ xg) {
+                                              double* __restrict__ d1g, const double* __restrict__ xg, bool skip_top = false) {
   constexpr int n = 2 * NV, RW = 16, NJ = (n + RW - 1) / RW, CG = LBS / RW, NIT = (NV + CG - 1) / CG;
+  const int r1 = i % NV;                             // the configuration row the first direction (an x direction) touches
   const double eps = sqrt(sqrt(DBL_EPSILON));
   const double eps2 = eps * eps;
   const int kk = lane % RW, cg = lane / RW;
@@ -433,7 +437,7 @@ __device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int 
       df *= 2;
       const double dd = df / eps2;
       d1k[j] = dd;
-      if (cg == 0 && k < n) d1g[k] = dd;
+      if (cg == 0 && k < n && !(skip_top && k < NV && k != r1)) d1g[k] = dd;   // (a configuration row other than r1: an exact zero, in memory)
     } else {
       d1k[j] = d1g[kc];
     }
@@ -461,6 +465,8 @@ __device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int 
     for (int j = 0; j < NJ; ++j) {
       const int k = kk + RW * j;
       if (!(cv && k < n)) continue;
+      // configuration rows other than those of the two directions: exact zeros, already in memory (LinParams::skip_top)
+      if (skip_top && k < NV && k != r1 && !(jp < n && jp % NV == k)) continue;
       // row k of f(x + dx, u + du) (dynamics_t::eval_to, problem.hpp:441-461)
       double x = xk[j];
       if (k == jp) x = x + eps;
@@ -579,11 +585,11 @@ __global__ __launch_bounds__(LBS, ROWS ? 1 : 3) void lin_static_tau_kernel(LinPa
     // column (k, u_c) of the (x_i, u) slab of f_ux: k + c n + i n m
     rowblock_emit<nv, true>(S, lane, i, n, kp->fux + bt * n * mm * n + (int64_t)i * n * mm, nullptr, 0, kp->fu + bt * n * mm,
                             kp->fuu + bt * n * mm * mm, (int64_t)n + (int64_t)n * mm, m.dt, kp->f_val + bt * n,
-                            kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg);
+                            kp->fx + bt * n * n + (int64_t)i * n, kp->fxx + bt * n * n * n + (int64_t)i * n + (int64_t)i * n * n, xg, kp->skip_top != 0);
   } else {
     __shared__ OutStage<nv, LBS / 2> S;
     LinParams po;
-    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror;
+    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror; po.skip_top = kp->skip_top;
     const double dt = m.dt;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -875,10 +881,10 @@ __global__ __launch_bounds__(LBS, ROWS ? 3 : 1) void lin_static_vel_kernel(LinPa
     rowblock_emit<nv, false>(S, lane, i, nv, fxx + (int64_t)nv * n + (int64_t)i * n * n,
                              kp->skip_qv_mirror ? nullptr : fxx + (int64_t)i * n + (int64_t)nv * n * n, (int64_t)n * n,
                              fxb + (int64_t)nv * n, fxx + (int64_t)nv * n + (int64_t)nv * n * n, (int64_t)n + (int64_t)n * n, dt,
-                             kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg);
+                             kp->f_val + bt * n, fxb + (int64_t)i * n, fxx + (int64_t)i * n + (int64_t)i * n * n, c.xg, kp->skip_top != 0);
   } else {
     LinParams po;
-    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror;
+    po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror; po.skip_top = kp->skip_top;
     offdiag_emit<nv, LBS>(po, S, valid, i, j, bt, c.xg, dt);
   }
 }
@@ -1171,7 +1177,7 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, c
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   LinParams po;
-  po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror;
+  po.f_val = kp->f_val; po.fx = kp->fx; po.fu = kp->fu; po.fxx = kp->fxx; po.fux = kp->fux; po.fuu = kp->fuu; po.skip_qv_mirror = kp->skip_qv_mirror; po.skip_top = kp->skip_top;
   offdiag_emit<nv, LBS>(po, S, valid, c.i, c.j, bt, c.xg, model->dt);
 }
 
@@ -1185,12 +1191,13 @@ __global__ __launch_bounds__(LBS) void lin_static_cfg_down_kernel(LinParams p, c
 template <int NV, bool DIAG>
 __device__ __forceinline__ void first_output(const double* q /* LDS, lane-major, stride NV + 1 */, int lane, int d0, double* __restrict__ out,
                                              int64_t ostride, const double* __restrict__ fcol, const double* __restrict__ f0,
-                                             const double* __restrict__ xg, double dt, double eps) {
+                                             const double* __restrict__ xg, double dt, double eps, bool skip_top = false) {
   constexpr int n = 2 * NV, TOT = NV * n;
   const double eps2 = eps * eps;
   for (int e = lane; e < TOT; e += LBS) {
     const int c = e / n, k = e - c * n;
     const int d = d0 + c;                        // perturbed direction of this column (an x index, or >= n for u)
+    if (DIAG && skip_top && k < NV && !(d < n && d % NV == k)) continue;   // configuration rows: exact zeros, in memory (LinParams::skip_top)
     double xk = xg[k];
     if (k == d) xk = xk + eps;
     double fv;
@@ -1283,7 +1290,7 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
     if (LEVEL == 3) { out = kp->fuu + bt * n * nv * nv; ostride = n + (int64_t)n * nv; }
     else { ostride = n + (int64_t)n * n; out = kp->fxx + bt * n * n * n + (LEVEL == 2 ? nv * ostride : 0); }
   }
-  first_output<nv, DIAG>(s_q, lane, LEVEL == 1 ? 0 : (LEVEL == 2 ? nv : n), out, ostride, fcol, kp->f_val + bt * n, xg, model->dt, eps);
+  first_output<nv, DIAG>(s_q, lane, LEVEL == 1 ? 0 : (LEVEL == 2 ? nv : n), out, ostride, fcol, kp->f_val + bt * n, xg, model->dt, eps, kp->skip_top != 0);
 }
 
 // ---- q- and v-caches ------------------------------------------------------------------------------------------------
