@@ -33,6 +33,8 @@ struct BwdParams {
   int32_t* status;
   int64_t* restarts;
   const BwdJob* jobs;
+  const BwdJob* jobs_half;   // K3h's job list (bwd_split.h: bwd_contract_half), or null
+  int32_t njobs_half, pad2_;
   int32_t has_tensors;
   int32_t b0;          // first instance of the group this launch sweeps
   int32_t c_accumulate; // K3's epilogue adds its contraction to what is already in the Q workspace (bwd_v2.h) instead of storing it
@@ -404,6 +406,10 @@ BwdParams make_params(ddp_hip_ctx* ctx) {
   p.status = ctx->status_d; p.restarts = ctx->restarts_d;
   p.sym_tensors = (ctx->tensors_sym && ctx->jobs_sym_d && getenv("DDP_HIP_K3_NO_SYM") == nullptr) ? 1 : 0;
   p.jobs = p.sym_tensors ? ctx->jobs_sym_d : ctx->jobs_d;
+  // K3h needs both structural facts: symmetry and the zero configuration rows (the static stencil's own tensors)
+  const bool half = p.sym_tensors && ctx->tensor_tops_zero && ctx->tensor_tops_sparse && ctx->jobs_half_d && getenv("DDP_HIP_K3_NO_HALF") == nullptr;
+  p.jobs_half = half ? ctx->jobs_half_d : nullptr;
+  p.njobs_half = half ? ctx->njobs_half : 0;
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
   return p;
 }
@@ -433,6 +439,7 @@ int launch_sweep_split(ddp_hip_ctx* ctx, const BwdParams& p0) {
   const Dims& d = ctx->d;
   const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
   const size_t lds_c = sizeof(double) * (size_t)(NC + (NC + MC) * cn_max + 2 * (NC / 2 + 1) * MC);
+  const size_t lds_h = sizeof(double) * (size_t)(NC + 3 * NC + 2 * (MC / 2 + 1) * NC);
   const size_t lds_r = sizeof(double) * (size_t)(2 * NC * (NC + MC));
   const int G = ctx->bwd_groups;
   const int64_t per = (d.batch + G - 1) / G;
@@ -458,7 +465,8 @@ int launch_sweep_split(ddp_hip_ctx* ctx, const BwdParams& p0) {
       if (!nb[g]) continue;
       if (p0.has_tensors) {
         prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
-        hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, nb[g]), dim3(BSF), lds_c, st[g], pg[g], t);
+        if (pg[g].jobs_half) hipLaunchKernelGGL((bwd_contract_half<NC, MC>), dim3((unsigned)pg[g].njobs_half, nb[g]), dim3(BSF), lds_h, st[g], pg[g], t);
+        else hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, nb[g]), dim3(BSF), lds_c, st[g], pg[g], t);
         prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
       }
       prof_begin(ctx, DDP_HIP_K_BWD_GAINS, st[g]);
@@ -481,7 +489,8 @@ int enqueue_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   const Dims& d = ctx->d;
   const int cn_max = ctx->cbx > ctx->cbu ? ctx->cbx : ctx->cbu;
   size_t lds_c = sizeof(double) * (size_t)(NC + (NC + MC) * cn_max + 2 * (NC / 2 + 1) * MC);
-  if (ctx->bwd_k3_lds_pad > lds_c) lds_c = ctx->bwd_k3_lds_pad;   // development: limits K3 to one workgroup per CU (room for K4' / K5 of another group)
+  if (ctx->bwd_k3_lds_pad > lds_c) lds_c = ctx->bwd_k3_lds_pad;
+  const size_t lds_h = sizeof(double) * (size_t)(NC + 3 * NC + 2 * (MC / 2 + 1) * NC);   // development: limits K3 to one workgroup per CU (room for K4' / K5 of another group)
   const size_t lds_5 = sizeof(double) * (size_t)(NC * NC + NC * (NC + MC) + NC + d.emax);
   const unsigned nblk5 = (unsigned)((NC + MC + CB5 - 1) / CB5);
   const int G = ctx->bwd_groups;
@@ -520,7 +529,8 @@ int enqueue_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
       }
       if (p0.has_tensors) {
         prof_begin(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
-        hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, nb[g]), dim3(BSF), lds_c, st[g], pg[g], t);
+        if (pg[g].jobs_half) hipLaunchKernelGGL((bwd_contract_half<NC, MC>), dim3((unsigned)pg[g].njobs_half, nb[g]), dim3(BSF), lds_h, st[g], pg[g], t);
+        else hipLaunchKernelGGL((bwd_contract<NC, MC>), dim3((unsigned)ctx->njobs, nb[g]), dim3(BSF), lds_c, st[g], pg[g], t);
         prof_end(ctx, DDP_HIP_K_BWD_ASSEMBLE, st[g]);
       }
       if (fork) HIP_TRY(hipStreamWaitEvent(st[g], ctx->bwd_ev_join, 0));
@@ -565,7 +575,7 @@ int launch_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   // profiled sweeps take the direct path: events recorded by a graph's event-record nodes cannot be read back with
   // hipEventElapsedTime on this ROCm (hipErrorInvalidHandle -- tried)
   if (!ctx->bwd_use_graph || (ctx->profile_mask & bwd_mask)) return enqueue_sweep_v2<NC, MC>(ctx, p0);
-  const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1) | ((uint64_t)p0.sym_tensors << 2);
+  const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1) | ((uint64_t)p0.sym_tensors << 2) | ((uint64_t)(p0.jobs_half != nullptr) << 3);
   auto find = [&](const void* key_x) -> ddp_hip_ctx::BwdGraph* {
     for (auto& g : ctx->bwd_graph)
       if (g.exec && g.key_x == key_x && g.key_misc == key_misc) return &g;
@@ -670,6 +680,13 @@ int bwd_setup(ddp_hip_ctx* ctx) {
     for (auto& j : js) if (j.kind == 0 && j.c0 >= m) j.kind = 2;
     HIP_TRY(hipMalloc(&ctx->jobs_sym_d, sizeof(BwdJob) * js.size()));
     HIP_TRY(hipMemcpy(ctx->jobs_sym_d, js.data(), sizeof(BwdJob) * js.size(), hipMemcpyHostToDevice));
+    // K3h (bwd_contract_half): x-columns in pairs (3 units each), u-columns in groups of 6 (3 units), the rest in one
+    std::vector<BwdJob> jh;
+    for (int64_t c = 0; c < n; c += 2) jh.push_back(BwdJob{10, (int32_t)c, 2, 0});
+    for (int64_t c = 0; c < m; c += 6) jh.push_back(BwdJob{11, (int32_t)c, (int32_t)((m - c) < 6 ? (m - c) : 6), 0});
+    ctx->njobs_half = (int32_t)jh.size();
+    HIP_TRY(hipMalloc(&ctx->jobs_half_d, sizeof(BwdJob) * jh.size()));
+    HIP_TRY(hipMemcpy(ctx->jobs_half_d, jh.data(), sizeof(BwdJob) * jh.size(), hipMemcpyHostToDevice));
   }
   return DDP_HIP_OK;
 }
@@ -696,6 +713,7 @@ void bwd_teardown(ddp_hip_ctx* ctx) {
   if (ctx->restarts_d) (void)hipFree(ctx->restarts_d);
   if (ctx->jobs_d) (void)hipFree(ctx->jobs_d);
   if (ctx->jobs_sym_d) (void)hipFree(ctx->jobs_sym_d);
+  if (ctx->jobs_half_d) (void)hipFree(ctx->jobs_half_d);
 }
 
 extern "C" int ddp_hip_backward(ddp_hip_ctx* ctx, double* reg_io, double* mu_io, int64_t* restarts_out, int64_t max_restarts) {

@@ -137,6 +137,168 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract(BwdParam
   }
 }
 
+// ---- K3h: the same contraction for this context's own mode-2 tensors, reading what is not known in advance ------------------
+// Two structural facts about the tensors the stencil (lin_static.hip / lin.hip) writes, both exact in floating point:
+//  (1) symmetry: entries (i, j, c) and (i, c, j) of f_xx / f_uu hold one value (problem.hpp:283-292) -> of slab c only the
+//      columns j >= c are read, the contraction goes to (j, c) and to (c, j);
+//  (2) the CONFIGURATION rows i < M of every column are exact zeros except at i = c mod M and i = j mod M (x directions): the
+//      first M rows of f are q + dt v, which does not see the dynamics, so row i of a stencil point differs from the base
+//      point's only when a direction is q_i or v_i; everything else differences bit-identical numbers.
+// So a column contributes  sum_{i >= M} V_x,i T(i, j, c)  plus at most two terms from its first M rows.  A unit is the lower
+// half (rows M .. N-1: 304 contiguous bytes per column) of N consecutive columns -- one slab of f_xx, two of f_ux or f_uu -- as
+// many bytes as bwd_contract's unit; the (at most) two entries of the upper half come with two 8-byte loads per column.  The sums
+// are formed in bwd_contract's order -- two-term partials over the row pairs (2 ip, 2 ip + 1), then ip ascending, the zero
+// partials adding nothing -- so the result is bwd_contract's bit for bit (tests/test_round3_boundary.py).
+// Bytes per (instance, t): 2.08 MB of lower halves + 0.13 MB of single entries against 6.31 MB (SURVEY.md 8d's formula).
+template <int N, int M>
+struct HalfShape {
+  static constexpr int HP = M / 2, LD = M / 2 + 1, TOTAL = (M / 2) * N, R = ((M / 2) * N + BSF - 1) / BSF;   // f64x2 words of a unit
+};
+static_assert(38 % 2 == 0, "row pairs");
+
+// kinds: 10 = x-columns c0, c0 + 1 (units: f_xx slab c0 | f_xx slab c0 + 1 | f_ux slabs c0, c0 + 1); 11 = cn u-columns from c0,
+// cn even (units: f_uu slabs in pairs)
+template <int N, int M>
+__global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(BwdParams p, int64_t t) {
+  int b, jb;
+  {
+    const int njobs = (int)gridDim.x, B = (int)gridDim.y;
+    const int lin = blockIdx.y * njobs + blockIdx.x;
+    if ((B & 7) == 0) {
+      const int xcd = lin & 7, k = lin >> 3;
+      b = xcd + 8 * (k / njobs);
+      jb = k % njobs;
+    } else { b = blockIdx.y; jb = blockIdx.x; }
+    b += p.b0;
+  }
+  if (p.status[b] != 0) return;
+  const BwdJob job = p.jobs_half[jb];
+  constexpr int n = N, m = M;
+  static_assert(N == 2 * M && M % 2 == 0, "lower halves of M rows, in row pairs");
+  const int64_t T = p.d.T;
+  const int tid = threadIdx.x;
+  const int kind = job.kind, c0 = job.c0, cn = job.cn;
+  const int64_t bt = (int64_t)b * T + t;
+  const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
+  double* C = p.c_accumulate == 2 ? p.ws_D + (int64_t)b * (n * n + m * n + m * m)
+                                  : p.ws_Q + (int64_t)b * (n + m + n * n + m * n + m * m) + n + m;
+  double* Cxx = C;
+  double* Cux = Cxx + n * n;
+  double* Cuu = Cux + m * n;
+  using HS = HalfShape<N, M>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* s_v = smem;                          // n
+  double* s_out = s_v + n;                     // units x N
+  double* s_p0 = s_out + 3 * N;                // HS::LD * N
+  double* s_p1 = s_p0 + HS::LD * N;
+  const int U = kind == 10 ? 3 : cn / 2;
+  // unit u: its N columns are slab / column pairs (sl, j): which tensor, which slab, the direction index of the column
+  auto unit_base = [&](int u) -> const double* {
+    if (kind == 10) return u < 2 ? p.fxx + (bt * n + c0 + u) * (int64_t)n * n : p.fux + (bt * n + c0) * (int64_t)n * m;
+    return p.fuu + (bt * m + c0 + 2 * u) * (int64_t)n * m;
+  };
+  // column jj of unit u: slab index (the first direction of the pair), column index within its tensor, and whether the column is
+  // read at all (symmetric tensors: j >= slab)
+  auto col_info = [&](int u, int jj, int& slab, int& j, bool& xcol) -> bool {
+    if (kind == 10) {
+      if (u < 2) { slab = c0 + u; j = jj; xcol = true; return j >= slab; }                // f_xx(:, j, slab)
+      slab = c0 + (jj >= m ? 1 : 0); j = jj >= m ? jj - m : jj; xcol = false; return true;   // f_ux(:, j, slab)
+    }
+    slab = c0 + 2 * u + (jj >= m ? 1 : 0); j = jj >= m ? jj - m : jj; xcol = false; return j >= slab;   // f_uu(:, j, slab)
+  };
+  f64x2 buf0[HS::R], buf1[HS::R], buf2[HS::R], buf3[HS::R];
+  double top0[2], top1[2], top2[2], top3[2];   // lane jj < N: the (at most) two entries of its column's upper half
+  auto issue = [&](int u, f64x2 (&buf)[HS::R], double (&top)[2]) {
+    const f64x2* base = reinterpret_cast<const f64x2*>(unit_base(u));
+#pragma unroll
+    for (int r = 0; r < HS::R; ++r) {
+      const int f = tid + r * BSF;
+      bool need = r < HS::R - 1 || f < HS::TOTAL;
+      const int jj = f / HS::HP, ip = f - jj * HS::HP;
+      int slab, j; bool xcol;
+      if (need) need = col_info(u, jj < n ? jj : n - 1, slab, j, xcol);
+      if (need) buf[r] = BWD_NT ? __builtin_nontemporal_load(&base[jj * (N / 2) + HS::HP + ip]) : base[jj * (N / 2) + HS::HP + ip];
+      else buf[r] = f64x2{0.0, 0.0};
+    }
+    top[0] = 0.0; top[1] = 0.0;
+    if (tid < n) {
+      int slab, j; bool xcol;
+      if (col_info(u, tid, slab, j, xcol) && kind == 10) {          // f_uu: its directions are controls, the upper half is all zeros
+        const double* colp = unit_base(u) + (int64_t)tid * n;
+        top[0] = colp[slab % M];                                     // the slab's direction is an x direction (f_xx and f_ux)
+        if (xcol && (j % M) != (slab % M)) top[1] = colp[j % M];
+      }
+    }
+  };
+  if (U > 0) issue(0, buf0, top0);
+  if (U > 1) issue(1, buf1, top1);
+  if (U > 2) issue(2, buf2, top2);
+  for (int i = tid; i < n; i += BSF) s_v[i] = Vx[i];
+  __syncthreads();
+  auto step = [&](int u, f64x2 (&buf)[HS::R], double (&top)[2]) {
+    double* sp = (u & 1) ? s_p1 : s_p0;
+#pragma unroll
+    for (int r = 0; r < HS::R; ++r) {
+      const int f = tid + r * BSF;
+      if (r < HS::R - 1 || f < HS::TOTAL) {
+        const int jj = f / HS::HP, ip = f - jj * HS::HP;
+        const f64x2 vv = *reinterpret_cast<const f64x2*>(s_v + M + 2 * ip);
+        sp[jj * HS::LD + ip] = vv.x * buf[r].x + vv.y * buf[r].y;
+      }
+    }
+    __syncthreads();
+    if (tid < n) {
+      int slab, j; bool xcol;
+      const bool need = col_info(u, tid, slab, j, xcol);
+      double sacc = 0.0;
+      if (need && kind == 10) {
+        // the upper half's partials, in bwd_contract's order: row pair (2 ip, 2 ip + 1), ip ascending; all others are zeros
+        const int ra = slab % M, rb = xcol ? j % M : ra;
+        const int lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
+        const double tlo = ra <= rb ? top[0] : top[1], thi = ra <= rb ? (ra == rb ? 0.0 : top[1]) : top[0];
+        if (lo == hi) {
+          const int e = lo & ~1;
+          const f64x2 vv = *reinterpret_cast<const f64x2*>(s_v + e);
+          const double tx = (lo & 1) ? 0.0 : tlo, ty = (lo & 1) ? tlo : 0.0;
+          sacc += vv.x * tx + vv.y * ty;
+        } else if ((lo >> 1) == (hi >> 1)) {
+          const f64x2 vv = *reinterpret_cast<const f64x2*>(s_v + lo);      // lo even, hi = lo + 1
+          sacc += vv.x * tlo + vv.y * thi;
+        } else {
+          const f64x2 va = *reinterpret_cast<const f64x2*>(s_v + (lo & ~1));
+          const f64x2 vb = *reinterpret_cast<const f64x2*>(s_v + (hi & ~1));
+          sacc += va.x * ((lo & 1) ? 0.0 : tlo) + va.y * ((lo & 1) ? tlo : 0.0);
+          sacc += vb.x * ((hi & 1) ? 0.0 : thi) + vb.y * ((hi & 1) ? thi : 0.0);
+        }
+      }
+      const double* pj = sp + tid * HS::LD;
+#pragma unroll
+      for (int k = 0; k < HS::HP; ++k) sacc += pj[k];
+      s_out[u * N + tid] = sacc;
+    }
+  };
+  // three units at most per job: all in flight from the start
+  if (U > 0) step(0, buf0, top0);
+  if (U > 1) step(1, buf1, top1);
+  if (U > 2) step(2, buf2, top2);
+  (void)buf3; (void)top3;
+  __syncthreads();
+  for (int idx = tid; idx < U * N; idx += BSF) {
+    const int u = idx / N, jj = idx - u * N;
+    int slab, j; bool xcol;
+    if (!col_info(u, jj, slab, j, xcol)) continue;           // the mirror image: written by the job of the other column
+    const double v = s_out[idx];
+    double* dst;
+    double* dm = nullptr;
+    if (kind == 10) {
+      if (u < 2) { dst = Cxx + j + slab * n; if (j > slab) dm = Cxx + slab + j * n; }
+      else dst = Cux + j + slab * m;
+    } else { dst = Cuu + j + slab * m; if (j > slab) dm = Cuu + slab + j * m; }
+    *dst = p.c_accumulate == 1 ? *dst + v : v;
+    if (dm) *dm = p.c_accumulate == 1 ? *dm + v : v;
+  }
+}
+
 // D = [f_x f_u]^T V_xx [f_x f_u] (blocks xx, ux, uu) for timestep td, with V_xx already in s_VW[0 .. N*N).
 // LDS: s_VW (N*(N+M) doubles: V_xx, then W = V_xx F), s_F (N*(N+M) doubles).  All BSR lanes take part.
 // This is the one genuinely dense product of the step (3.3 MFLOP per instance and step); it runs on the FP64 matrix

@@ -89,6 +89,9 @@ struct ddp_hip_ctx {
   int32_t* status_d = nullptr; // [batch] 0 active, 1 failed this attempt, 2 done
   int64_t* restarts_d = nullptr;
   BwdJob* jobs_d = nullptr;
+  BwdJob* jobs_half_d = nullptr;  // K3h's job list (bwd_split.h: bwd_contract_half)
+  int32_t njobs_half = 0;
+  bool tensor_tops_sparse = false; // the tensors' configuration rows are as the static mode-2 stencil leaves them: zeros but the two entries per column
   BwdJob* jobs_sym_d = nullptr;   // K3's job list for symmetric tensors (bwd_split.h, job kind 2)
   bool fxx_mirror_pending = false; // the static stencil left f_xx(:, q_i, v_c) out (lin.hip: lin_materialize_fxx forms it on demand)
   bool tensor_tops_zero = false;   // rows k < nv of every column of FXX / FUX / FUU hold zeros (what LinParams::skip_top relies on)

@@ -1011,6 +1011,9 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   if ((stages & DDP_HIP_LIN_SECOND) && p.has_tensors) {
     ctx->tensors_sym = ctx->model_h.fd_mode == 2 || ctx->model_h.fd_mode == 0;
     ctx->fxx_mirror_pending = p.skip_qv_mirror != 0;
+    // (the run-time-tree kernels and mode 0 leave the same structure -- it is a property of the stencil's values, not of who
+    // writes them -- but only the static mode-2 path has been held to it bit for bit: tests/test_round3_boundary.py)
+    ctx->tensor_tops_sparse = p.skip_top != 0;
   }
   return DDP_HIP_OK;
 }
