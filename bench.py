@@ -247,6 +247,7 @@ def main():
         it.phase_ms = keep
 
     out = None
+    ctx_stream_bytes = ctx.bwd_stream_bytes()
     if rank == 0:
         ms_a, n_a = ctx.profile_get(capi.K_BWD_ASSEMBLE)
         ms_f, n_f = ctx.profile_get(capi.K_FWD_ROLLOUT)
@@ -262,12 +263,17 @@ def main():
         bytes_per_launch = 8.0 * words * S / launches_per_sweep if full else 0.0
         avg_s = (ms_a / max(n_a, 1)) * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        # bytes K3 physically reads: mode-2 / zero tensors are symmetric in their two input indices bit for bit, and K3 then reads
-        # only the columns j >= c of slab c of f_xx and f_uu (n n (n-1)/2 + n m (m-1)/2 doubles per (instance, t) less:
-        # bwd_split.h).  `achieved` stays SURVEY.md 8(d)'s algorithmic figure over the launch time; `read_gbs` is the physical stream
-        sym_skip = (8.0 * (n_ * n_ * (n_ - 1) // 2 + n_ * m_ * (m_ - 1) // 2) * S / launches_per_sweep
-                    if (full and a.fd_mode == 2 and not os.environ.get("DDP_HIP_K3_NO_SYM")) else 0.0)
-        bytes_read = bytes_per_launch - sym_skip
+        # Bytes K3 physically streams.  This context's own mode-2 tensors have structure that is exact in floating point: they
+        # are symmetric in their two input indices, and the configuration rows of every column are zeros but two entries
+        # (q+ = q + dt v is affine) -- K3 reads the lower halves of the columns j >= c of slab c plus those entries
+        # (ddp_hip_bwd_stream_bytes: 2.1 of the 6.15 MB per (instance, t) of SURVEY.md 8(d)'s formula), and what is not read
+        # is not written by the stencil.  `achieved` / `frac` are the PHYSICAL stream (what the HBM roofline bounds);
+        # `survey_formula_*` is SURVEY.md 8(d)'s dense byte count over the same launch time, kept for comparison across rounds.
+        stream = ctx_stream_bytes
+        small = 8.0 * (n_ + 2 * (n_ * n_ + m_ * n_ + m_ * m_))          # V_x + the read-modify-write of the dense terms
+        bytes_read = (stream + small) * S / launches_per_sweep if full else 0.0
+        survey_gbs = achieved
+        achieved = bytes_read / avg_s / 1e9 if avg_s > 0 else 0.0
         # the sweep-level figure SURVEY.md 8(d) / BASELINE.md 3 define: B_bwd of every resident instance / the time of the
         # whole backward phase (K3 + K4 + launch gaps + the status read-back)
         t_bwd = it.phase_ms["backward"] / steps * 1e-3
@@ -276,7 +282,8 @@ def main():
         lin2_s = ms_l2 / steps * 1e-3
         lin2_flops = stencil_flops_per_bt(nv, a.fd_mode if full else 0) * S * T
         # tensor bytes the stencil writes: all of them, less the mirror images the symmetric sweep never reads (formed on demand)
-        lin2_bytes = (8.0 * (n_ ** 3 + n_ * n_ * m_ + n_ * m_ * m_) * S * T - sym_skip * launches_per_sweep * T) if full else 0.0
+        # (what the sweep never reads -- mirror images, zero configuration rows -- is not written either: the same byte count)
+        lin2_bytes = float(stream) * S * T if full else 0.0
         out = {
             "metric": "DDP iterations/sec (fwd+bwd sweep), Talos nq=38 T=200",
             "value": total * a.steps / elapsed,
@@ -295,8 +302,9 @@ def main():
             "roofline": {"kernel": "bwd_contract (K3: V_x-contracted f_xx, f_ux, f_uu)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(S / launches_per_sweep),
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": n_a,
-                         "bytes_read_per_launch": bytes_read, "read_gbs": bytes_read / avg_s / 1e9 if avg_s > 0 else 0.0,
+                         "bytes_per_launch": bytes_read, "avg_launch_us": avg_s * 1e6, "launches": n_a,
+                         "survey_formula_bytes_per_launch": bytes_per_launch, "survey_formula_gbs": survey_gbs,
+                         "survey_formula_frac": survey_gbs / HBM_PEAK_GBS,
                          # whole backward phase: B_bwd x instances / t_backward (SURVEY.md 8d's definition)
                          "sweep_achieved": sweep_gbs, "sweep_frac": sweep_gbs / HBM_PEAK_GBS,
                          "sweep_bytes": sweep_bytes, "sweep_ms": t_bwd * 1e3},

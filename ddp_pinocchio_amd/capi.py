@@ -45,7 +45,7 @@ EXPORTS = [
     "ddp_hip_backward",
     "ddp_hip_forward", "ddp_hip_cost_seq_aug", "ddp_hip_swap_traj",
     "ddp_hip_update_origin", "ddp_hip_optimality", "ddp_hip_update_multipliers", "ddp_hip_profile_enable",
-    "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_comm_unique_id",
+    "ddp_hip_profile_reset", "ddp_hip_profile_get", "ddp_hip_bwd_algorithmic_bytes", "ddp_hip_bwd_stream_bytes", "ddp_hip_comm_unique_id",
     "ddp_hip_comm_init", "ddp_hip_comm_destroy", "ddp_hip_shard_best", "ddp_hip_shard_pick", "ddp_hip_shard_broadcast",
     "ddp_hip_builtin_model",
     "ddp_hip_batch", "ddp_hip_set_active", "ddp_hip_solve", "ddp_hip_ctx_info",
@@ -142,6 +142,8 @@ def lib():
     L.ddp_hip_profile_reset.argtypes = [C.c_void_p]
     L.ddp_hip_profile_get.argtypes = [C.c_void_p, C.c_int, _dp, _lp]
     L.ddp_hip_bwd_algorithmic_bytes.restype = C.c_int64
+    L.ddp_hip_bwd_stream_bytes.restype = C.c_int64
+    L.ddp_hip_bwd_stream_bytes.argtypes = [C.c_void_p]
     L.ddp_hip_bwd_algorithmic_bytes.argtypes = [C.c_void_p]
     L.ddp_hip_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
     L.ddp_hip_comm_init.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -395,6 +397,9 @@ class Context:
     def cost_seq_aug(self, which, mu):
         mu = _f64(np.broadcast_to(mu, (self.batch,))).copy()
         return _check(lib().ddp_hip_cost_seq_aug(self._h, which, _ptr(mu)), "cost_seq_aug")
+
+    def bwd_stream_bytes(self):
+        return int(lib().ddp_hip_bwd_stream_bytes(self._h))
 
     def swap_traj(self):
         _check(lib().ddp_hip_swap_traj(self._h), "swap_traj")

@@ -233,6 +233,23 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(Bwd
   if (U > 0) issue(0, buf0, top0);
   if (U > 1) issue(1, buf1, top1);
   if (U > 2) issue(2, buf2, top2);
+  // this lane's output entry (U * N <= BSF: one per lane) and what the workspace holds there (c_accumulate: the dense terms K5
+  // left), requested now so that the read-modify-write at the end does not wait for a round trip of its own
+  double* dst = nullptr;
+  double* dm = nullptr;
+  double old_d = 0.0, old_m = 0.0;
+  static_assert(3 * N <= BSF, "one output entry per lane");
+  if (tid < U * N) {
+    const int u = tid / N, jj = tid - u * N;
+    int slab, j; bool xcol;
+    if (col_info(u, jj, slab, j, xcol)) {                  // (else: the mirror image, written by the job of the other column)
+      if (kind == 10) {
+        if (u < 2) { dst = Cxx + j + slab * n; if (j > slab) dm = Cxx + slab + j * n; }
+        else dst = Cux + j + slab * m;
+      } else { dst = Cuu + j + slab * m; if (j > slab) dm = Cuu + slab + j * m; }
+      if (p.c_accumulate == 1) { old_d = *dst; if (dm) old_m = *dm; }
+    }
+  }
   for (int i = tid; i < n; i += BSF) s_v[i] = Vx[i];
   __syncthreads();
   auto step = [&](int u, f64x2 (&buf)[HS::R], double (&top)[2]) {
@@ -283,19 +300,10 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(Bwd
   if (U > 2) step(2, buf2, top2);
   (void)buf3; (void)top3;
   __syncthreads();
-  for (int idx = tid; idx < U * N; idx += BSF) {
-    const int u = idx / N, jj = idx - u * N;
-    int slab, j; bool xcol;
-    if (!col_info(u, jj, slab, j, xcol)) continue;           // the mirror image: written by the job of the other column
-    const double v = s_out[idx];
-    double* dst;
-    double* dm = nullptr;
-    if (kind == 10) {
-      if (u < 2) { dst = Cxx + j + slab * n; if (j > slab) dm = Cxx + slab + j * n; }
-      else dst = Cux + j + slab * m;
-    } else { dst = Cuu + j + slab * m; if (j > slab) dm = Cuu + slab + j * m; }
-    *dst = p.c_accumulate == 1 ? *dst + v : v;
-    if (dm) *dm = p.c_accumulate == 1 ? *dm + v : v;
+  if (dst) {
+    const double v = s_out[tid];
+    *dst = old_d + v;                                      // (old_d = 0 unless c_accumulate == 1: 0 + v == v)
+    if (dm) *dm = old_m + v;
   }
 }
 

@@ -507,6 +507,24 @@ extern "C" int ddp_hip_profile_get(ddp_hip_ctx* ctx, int kernel_id, double* tota
   return DDP_HIP_OK;
 }
 
+// Bytes of f_xx / f_ux / f_uu the contraction kernel (K3) reads per (instance, step) with the tensors in their current state:
+// everything (tensors from outside), the columns j >= c of slab c (symmetric: this context's own mode-2 / zero tensors), or the
+// lower halves of those columns plus the (at most) two non-zero entries of each upper half (the static stencil's own tensors)
+extern "C" int64_t ddp_hip_bwd_stream_bytes(const ddp_hip_ctx* ctx) {
+  if (!ctx) return -1;
+  if (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) return 0;
+  const int64_t n = ctx->d.n, m = ctx->d.m;
+  const bool fast = n == 76 && m == 38 && ctx->d.emax <= 52 && getenv("DDP_HIP_GENERIC_BWD") == nullptr;
+  const bool sym = fast && ctx->tensors_sym && ctx->jobs_sym_d && getenv("DDP_HIP_K3_NO_SYM") == nullptr;
+  const bool half = sym && ctx->tensor_tops_zero && ctx->tensor_tops_sparse && ctx->jobs_half_d && getenv("DDP_HIP_K3_NO_HALF") == nullptr;
+  if (half) {
+    const int64_t cxx = n * (n + 1) / 2, cux = n * m, cuu = m * (m + 1) / 2;
+    return 8 * ((cxx + cux + cuu) * (n - m) + 2 * cxx - n + cux);       // lower halves + two entries per f_xx column (one on its diagonal), one per f_ux column
+  }
+  if (sym) return 8 * (n * (n * (n + 1) / 2) + n * n * m + n * (m * (m + 1) / 2));
+  return 8 * (n * n * n + n * n * m + n * m * m);
+}
+
 extern "C" int64_t ddp_hip_bwd_algorithmic_bytes(const ddp_hip_ctx* ctx) {
   if (!ctx) return -1;
   const Dims& d = ctx->d;

@@ -20,6 +20,9 @@
 #include "lin_common.h"
 #include "rbd.h"
 
+#ifndef DEV_NO_EMIT
+#define DEV_NO_EMIT 0
+#endif
 namespace {
 
 // ---- compiled-in topologies -------------------------------------------------------------------------------------
@@ -310,6 +313,7 @@ __device__ __forceinline__ void offdiag_emit(const LinParams& p, OutStage<NV, NP
     xk[jx] = xg[kc];
     xvk[jx] = kc < NV ? xg[NV + kc] : 0.0;
   }
+  if (DEV_NO_EMIT) return;
   for (int pt = 0; pt < PPG; pt += NB) {
     double a1[NB][NJ], a2[NB][NJ], d1[NB][NJ], d2[NB][NJ];
     double* o0[NB];
@@ -488,6 +492,7 @@ __device__ __forceinline__ void rowblock_emit(const ST& S, int lane, int i, int 
       if (mirror) mirror[k + c * mstride] = val;
     }
   };
+  if (DEV_NO_EMIT) return;
   fetch(0, va2[0], vd2[0]);
   for (int it = 0; it < NIT; it += 2) {
     if (it + 1 < NIT) fetch(it + 1, va2[1], vd2[1]);

@@ -238,6 +238,11 @@ int ddp_hip_profile_reset(ddp_hip_ctx* ctx);
 int ddp_hip_profile_get(ddp_hip_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
 /* algorithmic bytes of one backward sweep of ONE instance (SURVEY.md 8d formula B_bwd) */
 int64_t ddp_hip_bwd_algorithmic_bytes(const ddp_hip_ctx* ctx);
+/* bytes of f_xx / f_ux / f_uu the tensor contraction physically reads per (instance, step) with the tensors in their current
+ * state: all of them (tensors from outside); the columns j >= c of slab c (this context's own mode-2 tensors: symmetric bit for
+ * bit); or the lower halves of those columns plus the two non-zero entries of each upper half (the static stencil's tensors: the
+ * configuration rows of f are affine, their second differences exact zeros) -- see csrc/bwd_split.h */
+int64_t ddp_hip_bwd_stream_bytes(const ddp_hip_ctx* ctx);
 
 /* ---- multi-GPU shard (new, no reference counterpart) ----------------------- */
 #define DDP_HIP_COMM_ID_BYTES 128
