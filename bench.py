@@ -466,7 +466,7 @@ def pmc_traffic(S):
     under-count + WRITE_SIZE, separate --pmc runs: profiles/k3_traffic.json), valid for the profiled batch only"""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
-        return float(rec["bytes_per_launch"]) if int(rec["batch"]) == int(round(S)) else None
+        return float(rec["bytes_per_launch"]) if int(rec["batch"]) == int(round(S)) and not os.environ.get("DDP_HIP_K3_NO_HALF") else None
     except Exception:
         return None
 
