@@ -328,7 +328,8 @@ def main():
         if world == 1 and not a.no_extra and S != 1:
             extra["config3_single_instance"] = single_instance_leg(capi, a, model, local_rank, T)
             if full and a.fd_mode == 2:
-                for key, name in (("constrained_frame", "tree38_frame"), ("constrained_config", "tree38_config")):
+                for key, name in (("constrained_frame", "tree38_frame"), ("constrained_config", "tree38_config"),
+                                  ("config5_free_flyer_frame", "tree38ff_frame")):
                     try:
                         extra[key] = constrained_leg(capi, a, name, local_rank, T)
                     except Exception as exc:            # a failure here must not cost the headline line
@@ -375,7 +376,7 @@ def constrained_leg(capi, a, name, device, T, seeds=None, iters=2):
     trajectories: tools/probe_constrained.py; the CPU restatement of the reference's algorithm agrees, and the reference
     itself runs this shape in 500-digit mpfr: DESIGN.md 4d): then the tensors are still generated and timed, and the
     iterations run tensor-free (Gauss-Newton sweeps: V != 0, K != 0, LLT restarts and step halvings happen)."""
-    from problems import make
+    from problems import make, neutral_state
     S = seeds or a.seeds_per_gpu
     model, spec, o = make(name, T, batch=S, fd_mode=2)
     m, nx, n_, Etot = o.m, o.nx, o.n, o.Etot
@@ -385,7 +386,9 @@ def constrained_leg(capi, a, name, device, T, seeds=None, iters=2):
 
     def load(ctx):
         if "xs" not in state:
-            ctx.upload("X", np.zeros((S, (T + 1) * nx))); ctx.upload("U", us)
+            x_init = np.zeros((S, (T + 1) * nx))
+            x_init[:, :nx] = neutral_state(model)            # (a free-flyer root starts at the unit quaternion)
+            ctx.upload("X", x_init); ctx.upload("U", us)
             ctx.rollout()
             state["xs"] = ctx.download("X")
         xs = state["xs"]
@@ -434,6 +437,7 @@ def constrained_leg(capi, a, name, device, T, seeds=None, iters=2):
                 "llt_restarts": restarts_seen, "max_abs_K_instance0": float(np.max(np.abs(ctx.download("FB_JAC", 0, 1))))}
 
     out = {"workload": f"{name}: Talos-like tree, T={T}, {S} seeds x {a.n_alpha} alphas, "
+                       f"{'free-flyer root (nq=39), ' if 'ff' in name else ''}"
                        f"{'3-row frame constraint at T-2' if 'frame' in name else 'config constraint e=38 at every step'}, "
                        "two time shifts, N(0,0.01^2) multiplier jacobians, mu=1e3"}
     with capi.Context(spec, device=device) as ctx:

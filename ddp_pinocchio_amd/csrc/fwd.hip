@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64) void forward_kernel_lat(FwdParams p) {
 // Four candidates per workgroup halve the per-joint state (72 KB), which is what makes room for K_t and the model.
 template <int NJ>
 struct FwdLat2Lds {
-  static constexpr int NC = 4, NH = 16, n = 2 * NJ, nu = NJ;
+  static constexpr int NC = 4, NH = 16, n = 2 * NJ + 1, nu = NJ;   // n: room for the state of a free-flyer model (nq = nv + 1)
   double state[rbd::ABA_LDS_SLOTS2 * (NJ + NJ / 8) * NC];      // (+ NJ / 8: the bank skew of rbd::aba_tree_coop2w)
   double K[nu * n];
   double k[nu], uo[nu], xo[n];
@@ -290,11 +290,13 @@ __device__ unsigned long long g_fwd_stamps[12];
 #endif
 
 // OPEN: the open-loop rollout of make_trajectory (ddp.hpp:392-415) on the same machinery: one candidate, u = U as given, x to X
-template <int NJ, bool OPEN = false>
+// FF: free-flyer root (nq = nv + 1): x_new (-) x_old and q (+) dt v go through SE(3) for the root (lie.h), the dynamics through
+// rbd::aba_tree_coop2w's free-flyer form
+template <int NJ, bool OPEN = false, bool FF = false>
 __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   using L = FwdLat2Lds<NJ>;
   constexpr int NC = L::NC, NH = L::NH;
-  constexpr int n = 2 * NJ, nx = 2 * NJ, nu = NJ;
+  constexpr int n = 2 * NJ, nq = FF ? NJ + 1 : NJ, nx = nq + NJ, nu = NJ, XS = L::n;   // XS: stride of a candidate's state in LDS
   constexpr int K2 = nu * n / 2, KR = (K2 + 63) / 64;        // K_t as 16-byte words; words per lane
   static_assert((nu * n) % 2 == 0, "K_t is moved in 16-byte words");
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
   const double* cold = p.costs_old + (int64_t)b * (T + 1);
   const double* kg = p.fb_val + (int64_t)b * T * nu;
   const double* Kg = p.fb_jac + (int64_t)b * T * nu * n;
-  double* dx = S.dx + al * n;
-  double* x = S.x + al * nx;
+  double* dx = S.dx + al * XS;
+  double* x = S.x + al * XS;
   double* u = S.u + al * nu;
   double* qdd = S.qdd + al * nu;
   if (wave == 0) {
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
     }
     if (tid == 0) {
       cm.lvl_start[NJ] = m.lvl_start[NJ]; cm.child_start[NJ] = m.child_start[NJ];
-      cm.n_levels = m.n_levels; cm.nv = m.nv;
+      cm.n_levels = m.n_levels; cm.nv = m.nv; cm.nj = m.nj;
       cm.gravity[0] = m.gravity[0]; cm.gravity[1] = m.gravity[1]; cm.gravity[2] = m.gravity[2];
       cm.dt = m.dt; cm.c = m.c;
     }
@@ -407,8 +409,16 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
       if (live)
         for (int i = h; i < nu; i += NH) u[i] = S.uo[i];
     } else {
+    if constexpr (FF) {
+      if (live) {                                                              // :45 difference(out, old, new) on SE(3) x R^(nv-6) x R^nv
+        if (h == 0) lie::se3_difference(S.xo, x, dx);
+        for (int i = 6 + h; i < NJ; i += NH) dx[i] = x[i + 1] - S.xo[i + 1];
+        for (int i = h; i < NJ; i += NH) dx[NJ + i] = x[nq + i] - S.xo[nq + i];
+      }
+    } else {
     if (live)
       for (int i = h; i < n; i += NH) dx[i] = x[i] - S.xo[i];                  // :45 difference(out, old, new)
+    }
     rbd::coop_sync<true>();
     {
       constexpr int NR = (nu + NH - 1) / NH;
@@ -451,8 +461,28 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
     if (t + 1 < T) request(t + 1);
     FSTAMP(fs, 2);
     }
-    rbd::aba_tree_coop2w<NJ, NC, NH>(S.model, x, x + NJ, u, qdd, S.state, al, h, live, wave, fs);   // :50
+    rbd::aba_tree_coop2w<NJ, NC, NH, rbd::CoopModel<NJ>, FF>(S.model, x, x + nq, u, qdd, S.state, al, h, live, wave, fs);   // :50
     if (!lead) continue;
+    if constexpr (FF) {
+      // dynamics_t::eval_to on the group (problem.hpp:441-461, rbd::eval_f's free-flyer branch): the root's pose by one lane,
+      // ahead of the velocity updates it reads
+      double q7[7];
+      if (live && h == 0) {
+        double dq[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dq[k] = mdt * x[nq + k];
+        lie::se3_integrate(x, dq, q7);
+      }
+      rbd::coop_sync<true>();
+      if (live) {
+        for (int i = 6 + h; i < NJ; i += NH) { const double vo = mdt * x[nq + i]; const double qn = x[i + 1] + vo; x[i + 1] = qn; xw[(t + 1) * nx + i + 1] = qn; }
+        for (int i = h; i < NJ; i += NH) { const double vn = x[nq + i] + qdd[i] * mdt; x[nq + i] = vn; xw[(t + 1) * nx + nq + i] = vn; }
+        if (h == 0) {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) { x[k] = q7[k]; xw[(t + 1) * nx + k] = q7[k]; }
+        }
+      }
+    } else {
     if (live)
       for (int i = h; i < NJ; i += NH) {                                        // dynamics_t::eval_to, problem.hpp:441-461
         const double vo = mdt * x[NJ + i];
@@ -461,6 +491,7 @@ __global__ __launch_bounds__(128) void forward_kernel_lat2(FwdParams p) {
         x[i] = qn; x[NJ + i] = vn;
         xw[(t + 1) * nx + i] = qn; xw[(t + 1) * nx + NJ + i] = vn;
       }
+    }
     FSTAMP(fs, 7);
     if (t + 1 < T) { park(); cold_t = coldreg; }
     rbd::coop_sync<true>();
@@ -596,12 +627,12 @@ FwdParams make_params(ddp_hip_ctx* ctx) {
 bool fwd_lat_supported(const ddp_hip_ctx* ctx) {
   const DevModel& m = ctx->model_h;
   // (constrained problems: the rollout runs on the latency kernel, the candidates' cost terms on cand_cost_kernel)
-  if (m.kind != DDP_HIP_MODEL_TREE || m.ff || ctx->d.nv != 38 || getenv("DDP_HIP_FWD_SCRATCH") != nullptr) return false;
+  if (m.kind != DDP_HIP_MODEL_TREE || ctx->d.nv != 38 || (m.ff && getenv("DDP_HIP_FWD_FF_SCRATCH") != nullptr) || getenv("DDP_HIP_FWD_SCRATCH") != nullptr) return false;
   if (ctx->d.Etot != 0 && getenv("DDP_HIP_FWD_EQ_SCRATCH") != nullptr) return false;   // development: round 2's one-lane-per-rollout kernel for constrained problems
   // the cooperative traversal: at most 8 joints per tree level (one helper lane each), 16 levels and 3 children per joint
   // (rbd::coop_role packs a lane's joint of a level into one word)
   if (m.max_level_width > 8 || m.n_levels > 16) return false;
-  for (int j = 0; j < m.nv; ++j)
+  for (int j = 0; j < m.nj; ++j)
     if (m.child_start[j + 1] - m.child_start[j] > rbd::ROLE_MAX_CHILDREN) return false;
   return true;
 }
@@ -623,6 +654,10 @@ int fwd_setup(ddp_hip_ctx* ctx) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat2<38>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)sizeof(FwdLat2Lds<38>)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat2<38, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(FwdLat2Lds<38>)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat2<38, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(FwdLat2Lds<38>)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel_lat2<38, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)sizeof(FwdLat2Lds<38>)));
   }
   return DDP_HIP_OK;
@@ -651,7 +686,8 @@ extern "C" int ddp_hip_rollout(ddp_hip_ctx* ctx) {
   FwdParams p = make_params(ctx);
   if (fwd_lat_supported(ctx) && getenv("DDP_HIP_FWD_LAT1") == nullptr) {
     // unconstrained trees of the Talos size: the open-loop form of the latency kernel (one workgroup per instance)
-    hipLaunchKernelGGL((forward_kernel_lat2<38, true>), dim3((unsigned)ctx->d.batch), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+    if (ctx->model_h.ff) hipLaunchKernelGGL((forward_kernel_lat2<38, true, true>), dim3((unsigned)ctx->d.batch), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+    else hipLaunchKernelGGL((forward_kernel_lat2<38, true>), dim3((unsigned)ctx->d.batch), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
   } else {
     const int bs = 64;
     const unsigned grid = (unsigned)((ctx->d.batch + bs - 1) / bs);
@@ -713,7 +749,8 @@ extern "C" int ddp_hip_forward(ddp_hip_ctx* ctx, const double* mu, int32_t n_alp
     // cost terms of the rolled-out candidates come from cand_cost_kernel (parallel over t) instead of the rollout itself
     const bool lat_path = fwd_lat_supported(ctx) && n_alpha <= 8;
     if (lat_path && (getenv("DDP_HIP_FWD_LAT1") == nullptr || !p.cost_inline)) {
-      hipLaunchKernelGGL((forward_kernel_lat2<38>), dim3((unsigned)(2 * B)), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+      if (ctx->model_h.ff) hipLaunchKernelGGL((forward_kernel_lat2<38, false, true>), dim3((unsigned)(2 * B)), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
+      else hipLaunchKernelGGL((forward_kernel_lat2<38>), dim3((unsigned)(2 * B)), dim3(128), sizeof(FwdLat2Lds<38>), ctx->stream, p);
       if (!p.cost_inline) {
         hipLaunchKernelGGL((cand_cost_kernel<38>), dim3((unsigned)((B * n_alpha * d.T + 63) / 64)), dim3(64), 0, ctx->stream, p);
         hipLaunchKernelGGL(cand_sum_kernel, dim3((unsigned)((B * n_alpha + 63) / 64)), dim3(64), 0, ctx->stream, p);

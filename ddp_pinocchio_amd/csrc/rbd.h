@@ -809,6 +809,7 @@ struct CoopModel {
   int32_t lvl_start[NJ + 1], lvl_joint[NJ];
   int32_t child_start[NJ + 1], child_list[NJ];
   int32_t n_levels, nv;
+  int32_t nj, pad_;                 // joints (nv - 5 with a free-flyer root, else nv)
   unsigned long long role[DDP_MAXJ > 16 * 16 ? 1 : 16 * 16];   // coop_role of (level L, helper lane h) at role[L * NH + h] (NH <= 16, <= 16 levels)
 };
 
@@ -1020,9 +1021,15 @@ __device__ void aba_tree_coop(const M& m, const double* q, const double* v, cons
 constexpr int ABA_LDS_SLOTS2 = ABA_LDS_SLOTS;   // same record: the joint's own inertia now comes from the model table, its 21 slots hold the contribution
 __device__ __forceinline__ void wg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NJ, int TPB, int NH, class M>
+// FF: joint 0 is a free-flyer root (SE(3); q = [p, quaternion x y z w | joint angles], v = [linear, angular | joint rates] in the
+// body frame): S = identity on the body twist, its 6 x 6 articulated inertia is solved in registers (sym6_solve) -- the
+// operations of aba_tree's free-flyer branches, in their order; joint i >= 1 reads q[i + 6], v[i + 5]
+template <int NJ, int TPB, int NH, class M, bool FF = false>
 __device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, const double* v, const double* tau, double* qdd,
                                 double* st, int cand, int h, bool live, int wave, FwdStamp* fs = nullptr) {
+  const int nj = FF ? m.nv - 5 : m.nv;
+  auto QI = [](int i) { return FF ? i + 6 : i; };
+  auto VI = [](int i) { return FF ? i + 5 : i; };
   // joints eight apart (the two arms and the head of a humanoid advance side by side) would share LDS banks: skew the records
   auto S = [&](int joint, int slot) -> double& { return st[((joint + (joint >> 3)) * ABA_LDS_SLOTS2 + slot) * TPB + cand]; };
   constexpr int oE = 0, oR = 9, oC = 12, oP = 18, oZ = 24, oU = 45, oD = 51, oT = 52, oV = 53;
@@ -1031,9 +1038,19 @@ __device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, con
   // otherwise walk lvl_start -> lvl_joint -> parent / child_start -> child_list, four dependent LDS round trips per level and pass
   if (wave == 0) {
     if (live)
-      for (int i = h; i < m.nv; i += NH) {
+      for (int i = h; i < nj; i += NH) {
         double E[9], R[3];
-        joint_placement(m, i, q[i], E, R);
+        if (FF && i == 0) {                          // rbd::place: E = R(quaternion)^T, r = p
+          double Rq[9];
+          lie::quat_to_R(q + 3, Rq);
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) E[3 * k + l] = Rq[3 * l + k];
+          R[0] = q[0]; R[1] = q[1]; R[2] = q[2];
+        } else {
+          joint_placement(m, i, q[QI(i)], E, R);
+        }
 #pragma unroll
         for (int k = 0; k < 9; ++k) S(i, oE + k) = E[k];
 #pragma unroll
@@ -1053,7 +1070,8 @@ __device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, con
         const double* a = m.axis[i];
         double vJ[6] = {0, 0, 0, 0, 0, 0};
         const int o = role_rev(rr) ? 0 : 3;
-        vJ[o] = a[0] * v[i]; vJ[o + 1] = a[1] * v[i]; vJ[o + 2] = a[2] * v[i];
+        if (FF && i == 0) { vJ[0] = v[3]; vJ[1] = v[4]; vJ[2] = v[5]; vJ[3] = v[0]; vJ[4] = v[1]; vJ[5] = v[2]; }   // S = identity on the body twist
+        else { const double vi = v[VI(i)]; vJ[o] = a[0] * vi; vJ[o + 1] = a[1] * vi; vJ[o + 2] = a[2] * vi; }
         const int par = role_parent(rr);
         if (par >= 0) {
 #pragma unroll
@@ -1097,6 +1115,28 @@ __device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, con
         }
       }
       FSTAMP(fs, 9);
+      if (FF && i == 0) {
+        // the free-flyer root is resolved in the last pass: its articulated inertia (wave 1) and bias force (wave 0) stay in
+        // its record (aba_tree: IAr, pAr); it has no parent to contribute to
+        if (wave == 0) {
+          double pAi[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) pAi[k] = S(i, oP + k);
+#pragma unroll
+          for (int ci = 0; ci < ROLE_MAX_CHILDREN; ++ci) {
+            if (ci < nch) {
+              const int c = role_child(rr, ci);
+#pragma unroll
+              for (int k = 0; k < 6; ++k) pAi[k] += S(c, oP + k);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) S(i, oP + k) = pAi[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 21; ++k) S(i, oZ + k) = IA[k];
+        }
+      } else {
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const double i0 = rev ? IA[sidx(r, 0)] : IA[sidx(r, 3)];
@@ -1125,7 +1165,7 @@ __device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, con
         double sp = 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) sp += a[k] * (rev ? pAi[k] : pAi[3 + k]);
-        const double ui = tau[i] - sp;
+        const double ui = tau[VI(i)] - sp;
 #pragma unroll
         for (int k = 0; k < 6; ++k) S(i, oU + k) = U[k];
         S(i, oD) = dinv;
@@ -1163,6 +1203,7 @@ __device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, con
 #pragma unroll
         for (int k = 0; k < 21; ++k) S(i, oZ + k) = Z[k];
       }
+      }   // (not the free-flyer root)
     }
     FSTAMP(fs, 11);
     wg_sync_lds();
@@ -1190,16 +1231,32 @@ __device__ __forceinline__ void aba_tree_coop2w(const M& m, const double* q, con
         const double a0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
         xform_motion(E, R, a0, ap);
       }
+      if (FF && i == 0) {
+        // S = I: qdd_s = IA^-1 (tau_s - pA) - a' in the spatial ordering [angular; linear]; tau / qdd are ordered [linear; angular]
+        double IAr[21], rhs[6], qs[6];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) IAr[k] = S(i, oZ + k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rhs[k] = tau[3 + k] - S(i, oP + k); rhs[3 + k] = tau[k] - S(i, oP + 3 + k); }
+        sym6_solve(IAr, rhs, qs);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; qs[k] -= ap[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { qdd[k] = qs[3 + k]; qdd[3 + k] = qs[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S(i, oV + k) = ap[k] + qs[k];
+      } else {
       double s = 0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) { ap[k] += cb[k]; s += U[k] * ap[k]; }
       const double qd = (S(i, oT) - s) * S(i, oD);
-      qdd[i] = qd;
+      qdd[VI(i)] = qd;
       const double* a = m.axis[i];
       const int o = role_rev(rr) ? 0 : 3;
       ap[o] += a[0] * qd; ap[o + 1] += a[1] * qd; ap[o + 2] += a[2] * qd;
 #pragma unroll
       for (int k = 0; k < 6; ++k) S(i, oV + k) = ap[k];
+      }   // (not the free-flyer root)
     }
     coop_sync<true>();
   }

@@ -128,3 +128,33 @@ def test_backward_reads_one_of_each_mirrored_half_slab_bit_for_bit(gpu, monkeypa
         again = sweep()
         for a_, b_ in zip(sym, again):
             assert np.array_equal(a_, b_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tree38_config", "tree38_frame", "tree38ff", "tree38ff_frame"])
+def test_constrained_and_free_flyer_problems_take_the_latency_forward_kernel(gpu, name):
+    """forward_kernel_lat2 was `<38>`-only and unconstrained; constrained problems and free-flyer models fell
+    to the one-lane-per-rollout kernel (365 / 300 ms per pass at 64 seeds against 10).  Now the rollout of every Talos-size
+    tree runs on the latency kernel (free-flyer root: rbd::aba_tree_coop2w<FF>, SE(3) difference / integrate in the kernel;
+    constraints: the candidates' cost terms on cand_cost_kernel, parallel over t) -- and lands on the oracle's step."""
+    capi = gpu
+    T = 8
+    model, spec, o = make(name, T, batch=1, fd_mode=0)
+    x0, us, xs = initial_trajectory(o, model, seed=17, u_sigma=0.3)
+    mults = o.alloc_affine(o.Etot)
+    mults["origin"][:] = xs[:T * o.nx]
+    if o.Etot:
+        mults["jac"][:o.Etot * o.n] = 0.01 * np.random.default_rng(2).normal(size=o.Etot * o.n)
+    with capi.Context(spec, flags=capi.FLAG_NO_TENSORS) as ctx:
+        assert ctx.info()["fwd_path"] == 1
+        ctx.upload("X", xs); ctx.upload("U", us); ctx.upload("X_NEW", xs); ctx.upload("U_NEW", us)
+        for k, sname in (("origin", "MULT_ORIGIN"), ("val", "MULT_VAL"), ("jac", "MULT_JAC")):
+            if ctx.seq_size(sname):
+                ctx.upload(sname, mults[k][:ctx.seq_size(sname)])
+        ctx.linearize()
+        rc, reg, mu, _ = ctx.backward(0.0, 100.0)
+        fb = {"origin": ctx.download("FB_ORIGIN")[0], "val": ctx.download("FB_VAL")[0], "jac": ctx.download("FB_JAC")[0]}
+        step_ref, xs_ref, us_ref, _ = o.forward(xs, us, mults, fb, float(mu[0]))
+        rc, step, dcost = ctx.forward(mu, n_alpha=8)
+        assert step[0] == step_ref
+        assert rel_err(ctx.download("X_NEW")[0], xs_ref) < 1e-8 and rel_err(ctx.download("U_NEW")[0], us_ref) < 1e-8
