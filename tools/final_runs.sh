@@ -2,7 +2,7 @@
 # end-of-round runs on the GPU box (through gpurun, from the repo root): the GPU test suite, the default bench line, the bench
 # variants quoted in DESIGN.md, and the rocprofv3 kernel summary of the bench command; outputs under gpurun_out/final/
 set -e
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/final
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1 || true
@@ -17,3 +17,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -- pytho
 cd $ROOT
 python3 tools/summarize_profile.py $O/summary_bench_$R.txt --stats /tmp/prof_final --filter "" --note "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-extra --no-cpu-baseline (1 warm-up + 3 timed iterations, 64 seeds, full DDP mode 2); the bench line of this run: $(grep '^{' $O/bench_rocprof.log | tail -1 | head -c 1800)"
 head -12 $O/summary_bench_$R.txt | cut -c1-160
+# the N = 2 code path on this one GPU (gloo; RCCL cannot place two ranks on one device): bench.py starts its ranks itself
+DDP_BENCH_BACKEND=gloo DDP_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --seeds-per-gpu 16 --no-cpu-baseline --no-extra > $O/bench_2rank_rehearsal.json 2> $O/bench_2rank_rehearsal.err || true
