@@ -158,3 +158,31 @@ def test_constrained_and_free_flyer_problems_take_the_latency_forward_kernel(gpu
         rc, step, dcost = ctx.forward(mu, n_alpha=8)
         assert step[0] == step_ref
         assert rel_err(ctx.download("X_NEW")[0], xs_ref) < 1e-8 and rel_err(ctx.download("U_NEW")[0], us_ref) < 1e-8
+
+
+@pytest.mark.gpu
+def test_k3h_bit_for_bit_at_size(gpu, monkeypatch):
+    """the same at BASELINE's size: T = 200, the benchmark's inputs (x0 neutral, u ~ N(0, 0.1^2)) plus a terminal gradient so
+    that V_x != 0 along the whole horizon; K3h against the dense kernel at every step of four instances"""
+    capi = gpu
+    T, B = 200, 4
+    model, spec, o = make("tree38", T, batch=B, fd_mode=2)
+    with capi.Context(spec, flags=capi.FLAG_TRACE) as ctx:
+        us = np.stack([0.1 * np.random.default_rng(0xDD9000 + 3000 + g).normal(size=T * o.m) for g in range(B)])
+        ctx.upload("X", np.zeros((B, (T + 1) * o.nx))); ctx.upload("U", us)
+        ctx.rollout()
+        ctx.linearize()
+        ctx.upload("LFX", 0.1 * np.random.default_rng(7).normal(size=(B, o.n)))
+        ctx.upload("LFXX", np.tile(np.eye(o.n).reshape(-1), (B, 1)))
+        assert ctx.bwd_stream_bytes() < 0.4 * 8 * (o.n ** 3 + o.n * o.n * o.m + o.n * o.m * o.m)     # K3h is what runs
+
+        def sweep():
+            rc, reg, mu, rs = ctx.backward(0.0, 1.0, 8)
+            return ctx.download("FB_JAC"), ctx.download("FB_VAL"), ctx.download("VX_TRACE"), rs, reg, mu
+        half = sweep()
+        monkeypatch.setenv("DDP_HIP_K3_NO_SYM", "1")
+        dense = sweep()
+        monkeypatch.delenv("DDP_HIP_K3_NO_SYM")
+        for a_, b_ in zip(half, dense):
+            assert np.array_equal(a_, b_)
+        assert np.all(np.isfinite(half[0])) and float(np.max(np.abs(half[2]))) > 0
