@@ -40,7 +40,7 @@ K_BWD_ASSEMBLE, K_BWD_GAINS, K_FWD_ROLLOUT, K_LIN_FIRST, K_LIN_SECOND = range(5)
 # every symbol include/ddp_hip/ddp_hip.h declares
 EXPORTS = [
     "ddp_hip_abi_version", "ddp_hip_strerror", "ddp_hip_device_count", "ddp_hip_create", "ddp_hip_destroy",
-    "ddp_hip_stream", "ddp_hip_synchronize", "ddp_hip_seq_size", "ddp_hip_device_ptr", "ddp_hip_upload",
+    "ddp_hip_stream", "ddp_hip_synchronize", "ddp_hip_set_async", "ddp_hip_seq_size", "ddp_hip_device_ptr", "ddp_hip_upload",
     "ddp_hip_download", "ddp_hip_fill", "ddp_hip_rollout", "ddp_hip_linearize", "ddp_hip_linearize_stages",
     "ddp_hip_backward",
     "ddp_hip_forward", "ddp_hip_cost_seq_aug", "ddp_hip_swap_traj",
@@ -121,6 +121,7 @@ def lib():
     L.ddp_hip_stream.restype = C.c_void_p
     L.ddp_hip_stream.argtypes = [C.c_void_p]
     L.ddp_hip_synchronize.argtypes = [C.c_void_p]
+    L.ddp_hip_set_async.argtypes = [C.c_void_p, C.c_int]
     L.ddp_hip_seq_size.restype = C.c_int64
     L.ddp_hip_seq_size.argtypes = [C.c_void_p, C.c_int]
     L.ddp_hip_device_ptr.restype = C.c_void_p
@@ -400,6 +401,9 @@ class Context:
 
     def bwd_stream_bytes(self):
         return int(lib().ddp_hip_bwd_stream_bytes(self._h))
+
+    def set_async(self, on=True):
+        _check(lib().ddp_hip_set_async(self._h, 1 if on else 0), "set_async")
 
     def swap_traj(self):
         _check(lib().ddp_hip_swap_traj(self._h), "swap_traj")

@@ -407,6 +407,13 @@ extern "C" int ddp_hip_fill(ddp_hip_ctx* ctx, int seq, double value) {
   return fill_device(ctx, ctx->seq[seq].ptr, ctx->seq[seq].size * ctx->d.batch, value);
 }
 
+extern "C" int ddp_hip_set_async(ddp_hip_ctx* ctx, int on) {
+  if (!ctx) return DDP_HIP_E_ARG;
+  if (!on && ctx->async_mode) { HIP_TRY(hipSetDevice(ctx->device)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
+  ctx->async_mode = on != 0;
+  return DDP_HIP_OK;
+}
+
 extern "C" int ddp_hip_set_active(ddp_hip_ctx* ctx, const int32_t* active) {
   if (!ctx) return DDP_HIP_E_ARG;
   ctx->all_active = true;

@@ -146,6 +146,7 @@ struct ddp_hip_ctx {
   std::vector<int32_t> active_h;   // [batch], 1 = active
   bool all_active = true;
 
+  bool async_mode = false;     // ddp_hip_set_async: entry points that hand nothing back to the host do not wait for the stream
   uint32_t profile_mask = 0;   // bit (1 + kernel_id): that kernel class is bracketed by HIP events
   ProfSlot prof[DDP_HIP_K_COUNT];
 };
@@ -155,6 +156,9 @@ struct ddp_hip_ctx {
     hipError_t e__ = (expr);                            \
     if (e__ != hipSuccess) { (void)hipGetLastError(); return DDP_HIP_E_HIP; } \
   } while (0)
+
+// end of an entry point that returns nothing to the host: wait for the stream unless the context is in asynchronous mode
+#define END_SYNC(ctx) do { if (!(ctx)->async_mode) HIP_TRY(hipStreamSynchronize((ctx)->stream)); } while (0)
 
 // profile helpers (ctx.hip)
 void prof_begin(ddp_hip_ctx* ctx, int kid, hipStream_t stream = nullptr);   // stream: the one the kernel is launched on (default: the context's)

@@ -863,20 +863,29 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     prof_end(ctx, DDP_HIP_K_LIN_SECOND);
   }
   if (eq_stage) {
+    // small vector-space models with analytic jacobians (the pendulum, UR5-like arms in the drivers' mode) chain per lane; every
+    // model with forward-differenced jacobians takes the three-kernel chain (round 3: the per-lane form differenced 2 x 18 full
+    // dynamics evaluations and multiplied 12 x 12 matrices in ONE lane per (instance, t): 3.2 ms of latency at any size)
+    bool chained = false;
     if constexpr (small) {
-      hipLaunchKernelGGL((eq_first_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
-      if (p.has_tensors) {
-        if (fd_mode == 2) {
-          hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
-          hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p, 1);
-        } else if (fd_mode == 1) {
-          hipLaunchKernelGGL((second_m1_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 1);
-        } else {
-          HIP_TRY(hipMemsetAsync(p.eq_xx, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_XX].size * d.batch), ctx->stream));
-          HIP_TRY(hipMemsetAsync(p.eq_ux, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UX].size * d.batch), ctx->stream));
-          HIP_TRY(hipMemsetAsync(p.eq_uu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UU].size * d.batch), ctx->stream));
+      if (!p.eq_xk) {
+        chained = true;
+        hipLaunchKernelGGL((eq_first_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
+        if (p.has_tensors) {
+          if (fd_mode == 2) {
+            hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 0);
+            hipLaunchKernelGGL((eq_second_m2_kernel<NJ>), dim3(blocks_for(BT * P)), dim3(LBS), 0, ctx->stream, p, 1);
+          } else if (fd_mode == 1) {
+            hipLaunchKernelGGL((second_m1_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p, 1);
+          } else {
+            HIP_TRY(hipMemsetAsync(p.eq_xx, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_XX].size * d.batch), ctx->stream));
+            HIP_TRY(hipMemsetAsync(p.eq_ux, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UX].size * d.batch), ctx->stream));
+            HIP_TRY(hipMemsetAsync(p.eq_uu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UU].size * d.batch), ctx->stream));
+          }
         }
       }
+    }
+    if (chained) {
     } else if (ana_large) {
       // analytic jacobians: base point from the resident f_x, f_u, then the tensors
       { const int rc_ = lin_analytic_launch(ctx, p, 0, LIN_ANA_EQ); if (rc_ != DDP_HIP_OK) return rc_; }
@@ -962,7 +971,7 @@ int lin_setup(ddp_hip_ctx* ctx) {
     if (rc_ != DDP_HIP_OK) return rc_;
   }
   // look-ahead states / jacobians of the constraint chain on large models
-  if (ctx->d.Etot > 0 && (ctx->d.nv > 6 || ctx->model_h.ff) && ctx->model_h.first_order_fd) {
+  if (ctx->d.Etot > 0 && tree && ctx->model_h.first_order_fd) {
     const Dims& d = ctx->d;
     const int64_t K = ctx->model_h.eq_advance;
     const size_t words = (size_t)(d.batch * d.T * (K * d.nx + (K > 1 ? K - 1 : 0) * d.n * d.n + d.emax * d.n));
@@ -1004,7 +1013,7 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   else if (nv <= 38) rc = run_linearize<38>(ctx, p, stages);
   else rc = run_linearize<64>(ctx, p, stages);
   if (rc != DDP_HIP_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  END_SYNC(ctx);
   // mode 2 writes one value to both (i, j, k) and (i, k, j) (problem.hpp:283-292), mode 0 leaves zeros: f_xx is symmetric bit
   // for bit and the backward sweep reads one of each pair of mirrored half-slabs (bwd_split.h); mode 1's forward differences
   // of jacobians are not

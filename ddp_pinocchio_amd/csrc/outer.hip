@@ -215,7 +215,7 @@ extern "C" int ddp_hip_update_origin(ddp_hip_ctx* ctx, int which) {
   OuterParams p = make_params(ctx);
   hipLaunchKernelGGL(update_origin_kernel, dim3((unsigned)ctx->d.T, (unsigned)ctx->d.batch), dim3(OBS), 0, ctx->stream, p, which);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  END_SYNC(ctx);
   return DDP_HIP_OK;
 }
 
@@ -242,6 +242,6 @@ extern "C" int ddp_hip_update_multipliers(ddp_hip_ctx* ctx, const double* mu) {
   OuterParams p = make_params(ctx);
   hipLaunchKernelGGL(update_multipliers_kernel, dim3((unsigned)ctx->d.T, (unsigned)ctx->d.batch), dim3(OBS), 0, ctx->stream, p);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  END_SYNC(ctx);
   return DDP_HIP_OK;
 }

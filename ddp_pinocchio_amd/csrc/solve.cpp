@@ -7,6 +7,7 @@
 // an instance is latched and frozen (ddp_hip_set_active): the sweeps skip it and swap_traj keeps its trajectory, so its
 // result and its iteration count do not depend on its batch-mates.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -27,11 +28,13 @@ extern "C" int ddp_hip_solve(ddp_hip_ctx* ctx, const ddp_hip_solver_params* sp, 
 #define SOLVE_TRY(expr)                                          \
   do {                                                           \
     rc = (expr);                                                 \
-    if (rc < 0) { (void)ddp_hip_set_active(ctx, nullptr); return rc; } \
+    if (rc < 0) { (void)ddp_hip_set_active(ctx, nullptr); (void)ddp_hip_set_async(ctx, 0); return rc; } \
     if (rc > 0) ev |= rc;                                        \
   } while (0)
 
   SOLVE_TRY(ddp_hip_set_active(ctx, nullptr));
+  // the loop enqueues: only the calls that return values to the rules below wait for the device (ddp_hip_set_async)
+  SOLVE_TRY(ddp_hip_set_async(ctx, getenv("DDP_HIP_SOLVE_SYNC") ? 0 : 1));   // (DDP_HIP_SOLVE_SYNC: development A/B, every call waits as in round 2)
   SOLVE_TRY(ddp_hip_linearize(ctx));                                                        // :768
   tmp_reg = reg;
   SOLVE_TRY(ddp_hip_backward(ctx, tmp_reg.data(), mu.data(), nullptr, sp->max_restarts));   // :769-771 (mu is taken, reg is not)
@@ -74,6 +77,7 @@ extern "C" int ddp_hip_solve(ddp_hip_ctx* ctx, const ddp_hip_solver_params* sp, 
   }
 #undef SOLVE_TRY
   (void)ddp_hip_set_active(ctx, nullptr);
+  { const int rc_ = ddp_hip_set_async(ctx, 0); if (rc_ < 0) return rc_; }                  // (waits for the stream)
   for (size_t b = 0; b < nb; ++b) {
     log[b].iterations = iters[b]; log[b].result = result[b]; log[b].pad_ = 0;
     log[b].mu = mu[b]; log[b].reg = reg[b]; log[b].w = w[b]; log[b].n = n[b];

@@ -131,6 +131,13 @@ int ddp_hip_destroy(ddp_hip_ctx* ctx);
 /* the context's HIP stream (hipStream_t as void*) */
 void* ddp_hip_stream(ddp_hip_ctx* ctx);
 int ddp_hip_synchronize(ddp_hip_ctx* ctx);
+/* Asynchronous mode (off by default).  On: the entry points that hand nothing back to the host -- ddp_hip_linearize[_stages],
+ * ddp_hip_update_origin, ddp_hip_update_multipliers, ddp_hip_swap_traj -- enqueue their work on the context's stream and return
+ * without waiting; the entry points that return values (ddp_hip_optimality, ddp_hip_backward, ddp_hip_forward, downloads ...)
+ * synchronise as always, and everything is stream-ordered.  ddp_hip_solve runs its loop in this mode: per iteration the host
+ * waits three times -- for the stopping test's two scalars, for the sweep's restart status, for the line search's accept state
+ * -- instead of at every call.  Switching it off waits for the stream. */
+int ddp_hip_set_async(ddp_hip_ctx* ctx, int on);
 
 int64_t ddp_hip_batch(const ddp_hip_ctx* ctx);                       /* instances resident in the context */
 int64_t ddp_hip_seq_size(const ddp_hip_ctx* ctx, int seq);           /* elements per instance */
