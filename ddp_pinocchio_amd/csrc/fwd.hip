@@ -131,6 +131,15 @@ __global__ void cost_kernel(FwdParams p, int which) {
 // difference (ddp_fwd.ipp:54-56)
 template <int NJ>
 __global__ void forward_kernel(FwdParams p) {
+  // the model table in LDS: the dynamics of every step read it joint by joint (axis, placement, inertia: some 40 words per joint
+  // and evaluation), and from global memory each of those reads is a dependent L2 round trip of the one lane that rolls out
+  __shared__ DevModel s_model;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.model);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_model);
+    for (unsigned i = threadIdx.x; i < sizeof(DevModel) / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int na = p.n_alpha;
   if (gid >= p.d.batch * na) return;
@@ -139,7 +148,7 @@ __global__ void forward_kernel(FwdParams p) {
   const int cand = p.round * na + a;
   if (cand > 33) { p.fw_dcost[(int64_t)b * na + a] = INFINITY; return; }   // 2^-34 < 1e-10: never tried (ddp_fwd.ipp:35-37)
   const double step = ldexp(1.0, -cand);
-  const DevModel& m = *p.model;
+  const DevModel& m = s_model;
   const int nv = m.nv, n = 2 * nv, nx = m.nq + nv, nu = nv;
   const int64_t T = p.d.T;
   const double mu = p.mu[b];
