@@ -942,6 +942,11 @@ int lin_setup(ddp_hip_ctx* ctx) {
   const Dims& d = ctx->d;
   if (want) { ctx->lin_ncfg = (int32_t)d.nv + 1; ctx->lin_nvcfg = 2 * (int32_t)d.nv + 1; }
   else if (topo && ctx->model_h.first_order_fd) { ctx->lin_ncfg = 1; ctx->lin_nvcfg = 1; }   // first order only: base q, base (q, v)
+  else if (topo && tree && !ctx->model_h.ff && d.nv > 6 && ctx->model_h.fd_mode == 1 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS) &&
+           getenv("DDP_HIP_ANA_OWN_ABA") == nullptr) {
+    // analytic mode 1: the accelerations of its 2 nv perturbed points come from the static first-order kernels (lin_analytic.hip)
+    ctx->lin_ncfg = 1; ctx->lin_nvcfg = 1;
+  }
   if (ctx->lin_ncfg) {
     ctx->lin_ws_bytes = sizeof(double) * (size_t)(d.batch * d.T * ((int64_t)ctx->lin_ncfg * d.nv * rbd::QC_STRIDE + (int64_t)ctx->lin_nvcfg * d.nv * rbd::VC_STRIDE));
     HIP_TRY(hipMalloc(&ctx->lin_ws, ctx->lin_ws_bytes));

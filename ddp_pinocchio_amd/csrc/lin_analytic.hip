@@ -40,6 +40,8 @@ struct AnaParams {
   double* Fws;      // [slice pairs][2nv][nv][2nv] the v rows of f_x at the perturbed points (kept for the constraint chain), or null
   int32_t write_f;  // stage 1: form the f_xx / f_ux slabs (0: this pass only serves the constraint tensors)
   int32_t pad_;
+  const double* accel;   // stage 1: [pair][2nv][nv] accelerations of the perturbed points, formed by the static first-order kernels
+                         // (lin_static.hip, level 6) -- or null: every evaluation runs its own forward dynamics
 };
 
 // ---- kernel A -----------------------------------------------------------------------------------------------------
@@ -82,7 +84,13 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     }
   }
   __syncthreads();
-  rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_R1, 0, lane, true);   // ends with a barrier
+  if (ap.accel != nullptr && pp >= 1) {
+    const double* __restrict__ ag = ap.accel + ((int64_t)bt * W2 + (pp - 1)) * N;
+    for (int i = lane; i < N; i += AW) s_a[i] = ag[i];
+    __syncthreads();
+  } else {
+    rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_R1, 0, lane, true);   // ends with a barrier
+  }
   // world-frame recursion, root -> leaves, one lane per joint of a level
   for (int L = 0; L < m.n_levels; ++L) {
     const int idx = m.lvl_start[L] + lane;
@@ -510,6 +518,15 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
     // f_uu is exactly zero (see the header of this file)
     HIP_TRY(hipMemsetAsync(p.fuu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_FUU].size * d.batch), ctx->stream));
   }
+  if (stage == 1 && ctx->ana_A && ctx->lin_static && p.qcache) {
+    // the forward dynamics of the 2 nv perturbed points: the static first-order kernels evaluate exactly these points
+    // (x + sqrt(eps_mach) e_k) chain-wise from the base point's cache, ~25x cheaper than one cooperative ABA per point
+    LinParams pa = p;
+    pa.accel_out = ctx->ana_A;
+    const int rc_ = lin_static_launch(ctx, pa, 6);
+    if (rc_ != DDP_HIP_OK) return rc_;
+    ap.accel = ctx->ana_A;
+  }
   const int P = stage == 0 ? 1 : 2 * N + 1, C = stage == 0 ? 1 : N + 1;
   if (stage == 0 && !do_f) {
     // the base point of the constraint chain alone: it reads the resident f_x, f_u
@@ -548,6 +565,8 @@ int lin_analytic_setup(ddp_hip_ctx* ctx) {
   // the stage-0 and stage-1 launches of one linearisation share the workspace: the base point keeps slot 0 of every pair
   HIP_TRY(hipMalloc(&ctx->ana_T, sizeof(double) * (size_t)(ctx->ana_nbt * (2 * N + 1) * N * 2 * N)));
   HIP_TRY(hipMalloc(&ctx->ana_M, sizeof(double) * (size_t)(ctx->ana_nbt * (N + 1) * N * N)));
+  if (ctx->lin_static && ctx->lin_ws && ctx->model_h.fd_mode == 1 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS))
+    HIP_TRY(hipMalloc(&ctx->ana_A, sizeof(double) * (size_t)(BT * 2 * N * N)));
   if (d.Etot > 0) {
     // the constraint chain on analytic jacobians (ana_eq_kernel): K <= 2 look-ahead steps, see the kernel's header
     if (ctx->model_h.eq_advance < 1 || ctx->model_h.eq_advance > 2) return DDP_HIP_E_UNSUPPORTED;
@@ -570,6 +589,7 @@ void lin_analytic_teardown(ddp_hip_ctx* ctx) {
   if (ctx->ana_T) (void)hipFree(ctx->ana_T);
   if (ctx->ana_M) (void)hipFree(ctx->ana_M);
   if (ctx->ana_F) (void)hipFree(ctx->ana_F);
+  if (ctx->ana_A) (void)hipFree(ctx->ana_A);
 }
 
 int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {

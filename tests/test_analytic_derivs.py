@@ -131,6 +131,7 @@ def test_analytic_linearize_talos(gpu, T):
     picks = [(0, 0), (0, 199), (2, 100), (5, 23), (5, 24), (5, 199)]
     n, m, nx = o.n, o.m, o.nx
     with capi.Context(spec) as ctx:
+        assert ctx.info()["lin_path"] == 2      # the perturbed points' accelerations come from the static first-order kernels
         ctx.upload("X", np.stack([tr[2] for tr in trajs])); ctx.upload("U", np.stack([tr[1] for tr in trajs]))
         ctx.linearize()
         got = {(k, b): ctx.download(s, b, 1)[0] for b in sorted({b for b, _ in picks})
@@ -151,6 +152,34 @@ def test_analytic_linearize_talos(gpu, T):
             err, scale = float(np.max(np.abs(a - r))), max(1.0, float(np.max(np.abs(r))))
             tol = 1e-12 * scale if key == "f_val" else (1e-10 * scale if key in ("fx", "fu") else 8 * EPS * cond * jscale / E1)
             assert np.all(np.isfinite(a)) and err <= tol, (key, b, t, err, tol)
+
+
+@pytest.mark.gpu
+def test_mode1_static_accelerations_against_own_forward_dynamics(gpu, monkeypatch):
+    """mode 1 on a tree with a static topology takes the accelerations of its 2 nv perturbed points from the static first-order
+    kernels (lin_static.hip level 6) instead of one cooperative ABA per point (DDP_HIP_ANA_OWN_ABA=1 keeps the latter): two
+    roundings of the same accelerations, so the tensors agree to a few ulp of the jacobians over eps and f_x, f_u bit for bit"""
+    capi = gpu
+    T, B = 5, 2
+    model, spec, o = make("tree38", T, batch=B, fd_mode=1, first_order_fd=0)
+    trajs = [held_trajectory(o, model, seed=31 + b, u_sigma=0.3) for b in range(B)]
+    out = {}
+    for own in (False, True):
+        if own:
+            monkeypatch.setenv("DDP_HIP_ANA_OWN_ABA", "1")
+        with capi.Context(spec) as ctx:
+            assert ctx.info()["lin_path"] == (1 if own else 2)
+            ctx.upload("X", np.stack([tr[2] for tr in trajs])); ctx.upload("U", np.stack([tr[1] for tr in trajs]))
+            ctx.linearize()
+            out[own] = {k: ctx.download(k, 0, B) for k in ("FX", "FU", "FXX", "FUX", "FUU")}
+    nv = model.nv
+    cond = max(float(np.linalg.cond(o.crba(trajs[0][2][t * 2 * nv:t * 2 * nv + nv]))) for t in range(T))
+    jscale = max(1.0, float(np.max(np.abs(out[True]["FX"]))), float(np.max(np.abs(out[True]["FU"]))))
+    assert np.array_equal(out[False]["FX"], out[True]["FX"]) and np.array_equal(out[False]["FU"], out[True]["FU"])
+    assert np.array_equal(out[False]["FUU"], out[True]["FUU"])
+    for k in ("FXX", "FUX"):
+        err = float(np.max(np.abs(out[False][k] - out[True][k])))
+        assert err <= 8 * EPS * cond * jscale / E1, (k, err)
 
 
 @pytest.mark.gpu
@@ -197,6 +226,7 @@ def test_analytic_linearize_talos_constrained_slices(gpu):
     trajs = [held_trajectory(o, model, seed=90 + b, u_sigma=0.3) for b in range(B)]
     n, m, nx, e = o.n, o.m, o.nx, 3
     with capi.Context(spec) as ctx:
+        assert ctx.info()["lin_path"] == 2      # the perturbed points' accelerations come from the static first-order kernels
         ctx.upload("X", np.stack([tr[2] for tr in trajs])); ctx.upload("U", np.stack([tr[1] for tr in trajs]))
         ctx.linearize()
         got = {(k, b): ctx.download(sq, b, 1)[0] for b in range(B)
