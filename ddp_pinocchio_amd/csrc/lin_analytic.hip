@@ -19,6 +19,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <utility>
 
 #include "internal.h"
 #include "lin_common.h"
@@ -40,84 +41,206 @@ struct AnaParams {
   double* Fws;      // [slice pairs][2nv][nv][2nv] the v rows of f_x at the perturbed points (kept for the constraint chain), or null
   int32_t write_f;  // stage 1: form the f_xx / f_ux slabs (0: this pass only serves the constraint tensors)
   int32_t pad_;
+  double* M0;       // fused path: [B T][nv][nv] M^-1 at the trajectory points (stage 0 writes it, the v directions of stage 1 read it)
+  int32_t m0_only;  // fused path, stage 0: form M0 alone (the pre-pass of a stage-1 launch)
+  int32_t pad2_;
   const double* accel;   // stage 1: [pair][2nv][nv] accelerations of the perturbed points, formed by the static first-order kernels
                          // (lin_static.hip, level 6) -- or null: every evaluation runs its own forward dynamics
 };
 
-// ---- kernel A -----------------------------------------------------------------------------------------------------
+// ---- LDS layout of ana_eval_kernel (doubles) -----------------------------------------------------------------------------
+//   evaluation:  R1 [78 NJ: ABA state, then per joint Ic 36 | Bc 36 | ofc 6] | W [30 NJ: oR 9 | op 3 | J 6 | ov 6 | oa 6, later u | g over
+//                ov | oa] | q, v, tau, a [4 NJ] | parent, depth (int) [NJ]
+//   assembly on: T [nv x 2nv] over the dead R1 records when it fits there (2 NJ <= 78), else behind the evaluation block;
+//                M^-1 (fused path) behind T, resp. over the dead records
+template <int NJ> struct AnaLds {
+  static constexpr int R1 = (78 > rbd::ABA_LDS_SLOTS ? 78 : rbd::ABA_LDS_SLOTS) * NJ;
+  static constexpr int W = R1, Q = W + 30 * NJ, INTS = Q + 4 * NJ, EVAL = INTS + NJ;
+  static constexpr bool T_OVER = 2 * NJ <= 78;
+  static constexpr int T = T_OVER ? 0 : EVAL;
+  static constexpr int X = T_OVER ? 2 * NJ * NJ : 0, X_SZ = NJ * NJ;
+  static constexpr int m2(int a, int b) { return a > b ? a : b; }
+  static constexpr int TOTAL = m2(EVAL, m2(T + 2 * NJ * NJ, X + X_SZ));
+};
+
+// ---- in-wave helpers (fused path) -------------------------------------------------------------------------------------
+// A wave that is alone on its SIMD pays the full latency of every LDS read it waits for one by one.  batch_fence closes a batch
+// of reads (a compiler-level memory fence keeps later reads from being hoisted over it), value_fence pins a value so that the
+// arithmetic on a batch is not sunk below the next one: one wait per batch and a bounded number of registers in flight.
+__device__ __forceinline__ void batch_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void value_fence(double& v) { asm volatile("" : "+v"(v)); }
+// the value lane `src` (a constant) holds, as a wave-uniform scalar: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// M -> M^-1 with the wave's registers alone.  Lane r holds row r of the lower triangle of M in a[0 .. r] (rows r >= nv: the rows
+// of an identity block, so that nothing below depends on nv).  Right-looking Cholesky M = L L^T, row r of L replacing row r of M;
+// then lane r solves L L^T x = e_r.  Every L(i, l) another lane needs is one lane_bcast of the owner's register: the arithmetic
+// is that of the split path's ana_minv_kernel, entry for entry.  (Entries above the diagonal are never read; they hold junk.)
 template <int NJ>
+__device__ __forceinline__ void wave_spd_inverse(double (&a)[NJ], double (&x)[NJ], int r) {
+  double my_dinv = 0.0;                                   // 1 / L(r, r)
+#pragma unroll
+  for (int k = 0; k < NJ; ++k) {
+    const double dk_own = sqrt(a[k]), di_own = 1.0 / dk_own;
+    const double dk = lane_bcast(dk_own, k), dinv_k = lane_bcast(di_own, k);
+    my_dinv = (r == k) ? di_own : my_dinv;
+    a[k] = (r == k) ? dk : a[k] * dinv_k;
+#pragma unroll
+    for (int j = k + 1; j < NJ; ++j) { a[j] = a[j] - a[k] * lane_bcast(a[k], j); value_fence(a[j]); }   // rows r >= j; L(j, k) from lane j
+    __builtin_amdgcn_sched_barrier(0);                    // (bounds the scalars the scheduler keeps in flight)
+  }
+  // (the substitutions broadcast the same L(i, l) the factorisation did; the fences keep the compiler from parking all nv^2 / 2
+  // of them in spilled scalars to save the second and third v_readlane)
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) value_fence(a[i]);
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) x[i] = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    double sx = x[i];
+#pragma unroll
+    for (int l = 0; l < i; ++l) sx -= lane_bcast(a[l], i) * x[l];                 // L(i, l) from lane i
+    x[i] = sx * lane_bcast(my_dinv, i);
+    value_fence(x[i]);                                    // (keeps the row's arithmetic from being sunk below the next row's broadcasts)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) value_fence(a[i]);
+#pragma unroll
+  for (int i = NJ - 1; i >= 0; --i) {
+    double sx = x[i];
+#pragma unroll
+    for (int l = i + 1; l < NJ; ++l) sx -= lane_bcast(a[i], l) * x[l];             // L(l, i) from lane l
+    x[i] = sx * lane_bcast(my_dinv, i);
+    value_fence(x[i]);                                    // (keeps the row's arithmetic from being sunk below the next row's broadcasts)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+#ifdef DEV_ANA_CLOCKS   // development: cycle stamps of one wave per launch
+#define CLK(k) do { if (lane == 0) clk[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CLK(k) do { } while (0)
+#endif
+// ---- kernel A -----------------------------------------------------------------------------------------------------
+template <int NJ, bool FUSED>
 __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
   const LinParams& p = ap.lp;
   const DevModel& m = *p.model;
   const int N = m.nv, W2 = 2 * N;
-  // stage 1 re-evaluates the trajectory point (p = 0) as well: the v directions use its M^-1, and the workspace slice
-  // may have been recycled since stage 0
-  const int P = ap.stage == 0 ? 1 : 2 * N + 1;            // evaluations per pair in this launch
+  // split path: stage 1 re-evaluates the trajectory point (p = 0) as well -- the v directions use its M^-1, and the workspace
+  // slice may have been recycled since stage 0.  Fused path: that M^-1 is resident (AnaParams::M0), stage 1 runs p = 1 .. 2nv
+  const int P = ap.stage == 0 ? 1 : (FUSED ? 2 * N : 2 * N + 1);   // evaluations per pair in this launch
   const int64_t e = blockIdx.x;
   const int64_t sbt = e / P;                              // pair within the slice
-  const int pp = (int)(e % P);                            // perturbation index
+  const int pp = ap.stage == 0 ? 0 : (int)(e % P) + (FUSED ? 1 : 0);   // perturbation index
   const int64_t bt = ap.bt0 + sbt;
   const int64_t T = p.d.T;
   const int b = (int)(bt / T);
   const int64_t t = bt % T;
   const int lane = threadIdx.x;
 
+#ifdef DEV_ANA_CLOCKS
+  unsigned long long clk[12] = {0};
+#endif
+  CLK(0);
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int R1 = 78 * NJ > rbd::ABA_LDS_SLOTS * NJ ? 78 * NJ : rbd::ABA_LDS_SLOTS * NJ;
-  double* s_R1 = lds;                 // ABA state, then per joint Ic[36] | Bc[36] | ofc[6], then T (nv x 2nv)
-  double* s_W = s_R1 + R1;            // per joint oR[9] | op[3] | J[6] | ov[6] | oa[6]
-  double* s_P = s_W + 30 * NJ;        // per joint y | z | u | g | Fq | Fv
-  double* s_q = s_P + 36 * NJ;
+  typedef AnaLds<NJ> LY;
+  double* s_R1 = lds;                 // ABA state, then per joint Ic[36] | Bc[36] | ofc[6]
+  double* s_W = lds + LY::W;          // per joint oR[9] | op[3] | J[6] | ov[6] | oa[6]; u | g replace ov | oa once they are spent
+  double* s_q = lds + LY::Q;
   double* s_v = s_q + NJ;
   double* s_tau = s_v + NJ;
   double* s_a = s_tau + NJ;
+  int* s_par = reinterpret_cast<int*>(s_a + NJ);   // parent of joint i
+  int* s_lvl = s_par + NJ;                         // tree depth of joint i
 
+  // lane i owns joint i (nv <= 64): its constants, its state and its own placement stay in registers, so the model table is read
+  // once, by all lanes at the same time, and the level loop below touches nothing but LDS
+  const bool live = lane < N;
+  const int ji = live ? lane : 0;
+  const int par_i = m.parent[ji];
+  const bool revolute = m.jtype[ji] == DDP_HIP_JOINT_REVOLUTE;
+  double Rl[9], rl[3], ax[3], vi;
   {
     const double* xs = p.x + ((int64_t)b * (T + 1) + t) * (2 * N);
     const double* us = p.u + ((int64_t)b * T + t) * N;
     const double eps = sqrt(DBL_EPSILON);
-    for (int i = lane; i < N; i += AW) {
-      double qi = xs[i], vi = xs[N + i];
-      if (pp >= 1 && pp - 1 == i) qi = qi + eps;          // integrate_x, problem.hpp:107,117
-      if (pp >= 1 && pp - 1 == N + i) vi = vi + eps;
-      s_q[i] = qi; s_v[i] = vi; s_tau[i] = us[i];
+    double qi = xs[ji];
+    vi = xs[N + ji];
+    if (pp >= 1 && pp - 1 == ji) qi = qi + eps;           // integrate_x, problem.hpp:107,117
+    if (pp >= 1 && pp - 1 == N + ji) vi = vi + eps;
+    if (live) { s_q[lane] = qi; s_v[lane] = vi; s_tau[lane] = us[lane]; s_par[lane] = par_i; }
+    double E[9];
+    rbd::joint_placement(m, ji, qi, E, rl);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) Rl[3 * k + l] = E[3 * l + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ax[k] = m.axis[ji][k];
+    if (live) {                                           // depth of joint lvl_joint[lane]: the levels that end at or before its slot
+      int lv = 0;
+      for (int L = 1; L < m.n_levels; ++L) lv += (lane >= m.lvl_start[L]) ? 1 : 0;
+      s_lvl[m.lvl_joint[lane]] = lv;
     }
   }
   __syncthreads();
   if (ap.accel != nullptr && pp >= 1) {
     const double* __restrict__ ag = ap.accel + ((int64_t)bt * W2 + (pp - 1)) * N;
-    for (int i = lane; i < N; i += AW) s_a[i] = ag[i];
-    __syncthreads();
+    if (live) s_a[lane] = ag[lane];
   } else {
     rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_R1, 0, lane, true);   // ends with a barrier
   }
-  // world-frame recursion, root -> leaves, one lane per joint of a level
+  const int my_lvl = live ? s_lvl[lane] : -1;
+  __syncthreads();
+  const double ai = live ? s_a[lane] : 0.0;
+  CLK(1);
+  // world-frame recursion, root -> leaves: the joints of one level in parallel
   for (int L = 0; L < m.n_levels; ++L) {
-    const int idx = m.lvl_start[L] + lane;
-    if (idx < m.lvl_start[L + 1]) {
-      const int i = m.lvl_joint[idx];
-      const int par = m.parent[i];
-      double oR[9], op[3], J[6], ov[6], oa[6], oRp[9], opp[3];
-      if (par >= 0) {
+    if (my_lvl == L) {
+      double oR[9], op[3], J[6], ov[6], oa[6];
+      const double* wp = s_W + 30 * (par_i >= 0 ? par_i : 0);
+      if (par_i >= 0) {
+        double oRp[9], t3[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) oRp[k] = s_W[30 * par + k];
+        for (int k = 0; k < 9; ++k) oRp[k] = wp[k];
+        rbd::mm3(oRp, Rl, oR);
+        rbd::mv3(oRp, rl, t3);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) opp[k] = s_W[30 * par + 9 + k];
+        for (int k = 0; k < 3; ++k) op[k] = wp[9 + k] + t3[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) oR[k] = Rl[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) op[k] = rl[k];
       }
-      rbdd::world_placement(m, i, s_q[i], par >= 0 ? oRp : nullptr, par >= 0 ? opp : nullptr, oR, op);
-      rbdd::world_axis(m, i, oR, op, J);
+      {                                                   // rbdd::world_axis
+        double aw[3];
+        rbd::mv3(oR, ax, aw);
+        if (revolute) {
+          double t3[3];
+          rbd::cross3(op, aw, t3);
+          J[0] = aw[0]; J[1] = aw[1]; J[2] = aw[2]; J[3] = t3[0]; J[4] = t3[1]; J[5] = t3[2];
+        } else {
+          J[0] = 0.0; J[1] = 0.0; J[2] = 0.0; J[3] = aw[0]; J[4] = aw[1]; J[5] = aw[2];
+        }
+      }
       double vJ[6], t6[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vJ[k] = J[k] * s_v[i];
+      for (int k = 0; k < 6; ++k) vJ[k] = J[k] * vi;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ov[k] = (par >= 0 ? s_W[30 * par + 18 + k] : 0.0) + vJ[k];
+      for (int k = 0; k < 6; ++k) ov[k] = (par_i >= 0 ? wp[18 + k] : 0.0) + vJ[k];
       rbd::crm(ov, vJ, t6);
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const double apk = par >= 0 ? s_W[30 * par + 24 + k] : (k < 3 ? 0.0 : -m.gravity[k - 3]);
-        oa[k] = apk + J[k] * s_a[i] + t6[k];
+        const double apk = par_i >= 0 ? wp[24 + k] : (k < 3 ? 0.0 : -m.gravity[k - 3]);
+        oa[k] = apk + J[k] * ai + t6[k];
       }
-      double* w = s_W + 30 * i;
+      double* w = s_W + 30 * lane;
 #pragma unroll
       for (int k = 0; k < 9; ++k) w[k] = oR[k];
 #pragma unroll
@@ -127,6 +250,7 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     }
     __syncthreads();
   }
+  CLK(2);
   // per body: world inertia, force, bias matrix (the ABA state in s_R1 is dead)
   for (int i = lane; i < N; i += AW) {
     const double* w = s_W + 30 * i;
@@ -149,76 +273,290 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     for (int k = 0; k < 6; ++k) o[72 + k] = Ioa[k] + vxh[k];
   }
   __syncthreads();
-  // composite sums leaves -> root: lane = entry; a lane only ever touches its own entries, children precede parents
-  for (int i = N - 1; i >= 1; --i) {
-    const int par = m.parent[i];
-    if (par < 0) continue;
-    for (int k = lane; k < 78; k += AW) s_R1[78 * par + k] += s_R1[78 * i + k];
+  CLK(3);
+  // composite sums leaves -> root: lane l < 39 owns entries 2l, 2l+1 of every record (a lane only ever touches its own entries,
+  // and the LDS executes a wave's accesses in order); children precede parents in this descending sweep
+  if (lane < 39) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    for (int i = N - 1; i >= 1; --i) {
+      const int par = __builtin_amdgcn_readlane(par_i, i);
+      if (par < 0) continue;
+      d2* dst = reinterpret_cast<d2*>(s_R1 + 78 * par) + lane;
+      const d2 c = reinterpret_cast<const d2*>(s_R1 + 78 * i)[lane];
+      *dst = *dst + c;
+    }
   }
   __syncthreads();
-  for (int i = lane; i < N; i += AW) {
-    const double* w = s_W + 30 * i;
-    const double* c = s_R1 + 78 * i;
+  CLK(4);
+  double Pr[36];                                          // y | z | u | g | Fq | Fv of the lane's joint; the others read its u | g from s_W
+  if (live) {
+    double* w = s_W + 30 * lane;
+    const double* c = s_R1 + 78 * lane;
     double J[6], ov[6], oa[6], Ic[36], Bc[36], ofc[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { J[k] = w[12 + k]; ov[k] = w[18 + k]; oa[k] = w[24 + k]; ofc[k] = c[72 + k]; }
 #pragma unroll
     for (int k = 0; k < 36; ++k) { Ic[k] = c[k]; Bc[k] = c[36 + k]; }
-    double y[6], z[6], u[6], g[6], t1[6], t2[6], t3[6];
-    rbdd::m6v(Ic, J, y);
-    rbdd::m6tv(Bc, J, z);
-    rbd::crm(J, ov, u);
-    rbd::crm(u, ov, t1);
+    double t1[6], t2[6], t3[6];
+    rbdd::m6v(Ic, J, Pr);                                 // y
+    rbdd::m6tv(Bc, J, Pr + 6);                            // z
+    rbd::crm(J, ov, Pr + 12);                             // u
+    rbd::crm(Pr + 12, ov, t1);
     rbd::crm(J, oa, t2);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) g[k] = t1[k] - t2[k];
-    double* o = s_P + 36 * i;
+    for (int k = 0; k < 6; ++k) Pr[18 + k] = t1[k] - t2[k];   // g
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { o[k] = y[k]; o[6 + k] = z[k]; o[12 + k] = u[k]; o[18 + k] = g[k]; }
+    for (int k = 0; k < 12; ++k) w[18 + k] = Pr[12 + k];
     rbd::crf(J, ofc, t1);
-    rbdd::m6v(Bc, u, t2);
-    rbdd::m6v(Ic, g, t3);
+    rbdd::m6v(Bc, Pr + 12, t2);
+    rbdd::m6v(Ic, Pr + 18, t3);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[24 + k] = t1[k] - t2[k] + t3[k];
+    for (int k = 0; k < 6; ++k) Pr[24 + k] = t1[k] - t2[k] + t3[k];
     rbdd::m6v(Bc, J, t1);
-    rbdd::m6v(Ic, u, t2);
+    rbdd::m6v(Ic, Pr + 12, t2);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[30 + k] = t1[k] - 2.0 * t2[k];
+    for (int k = 0; k < 6; ++k) Pr[30 + k] = t1[k] - 2.0 * t2[k];
   }
   __syncthreads();
+  CLK(5);
   // T (row-major nv x 2nv: [d tau/dq | d tau/dv]) in LDS over the dead composite region, M straight to the workspace
-  double* s_T = s_R1;
+  double* s_T = lds + LY::T;
   for (int k = lane; k < N * W2; k += AW) s_T[k] = 0.0;
   __syncthreads();
   const bool want_M = pp <= N;
   double* Mo = ap.Mws + (sbt * (N + 1) + (want_M ? pp : 0)) * (int64_t)N * N;
-  if (want_M)
-    for (int k = lane; k < N * N; k += AW) Mo[k] = 0.0;
-  __syncthreads();
-  for (int j = lane; j < N; j += AW) {
-    const double* Pj = s_P + 36 * j;
-    for (int i = j; i >= 0; i = m.parent[i]) {            // i in path(j): column j, row i
-      const double* Ji = s_W + 30 * i + 12;
+  if constexpr (!FUSED) {
+    if (want_M)
+      for (int k = lane; k < N * N; k += AW) Mo[k] = 0.0;
+    __syncthreads();
+  }
+  double arow[FUSED ? NJ : 1];                            // fused path: row `lane` of the lower triangle of M (its nonzeros lie on the lane's path)
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) arow[k] = 0.0;
+  }
+  CLK(6);
+  if (live) {
+    const int j = lane;
+    for (int i = j; i >= 0; i = s_par[i]) {               // i in path(j): column j of row i, and (i != j) column i of row j
+      const double* wi = s_W + 30 * i;
+      double Jr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jr[k] = wi[12 + k];
       double sq = 0, sv = 0, sm = 0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { sq += Ji[k] * Pj[24 + k]; sv += Ji[k] * Pj[30 + k]; sm += Ji[k] * Pj[k]; }
+      for (int k = 0; k < 6; ++k) { sq += Jr[k] * Pr[24 + k]; sv += Jr[k] * Pr[30 + k]; sm += Jr[k] * Pr[k]; }
       s_T[i * W2 + j] = sq;
       s_T[i * W2 + N + j] = sv;
-      if (want_M) { Mo[i + (int64_t)j * N] = sm; Mo[j + (int64_t)i * N] = sm; }
-    }
-    for (int a = m.parent[j]; a >= 0; a = m.parent[a]) {  // a proper ancestor of j: row j, column a
-      const double* Pa = s_P + 36 * a;
-      const double* Ja = s_W + 30 * a + 12;
-      double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+      if constexpr (FUSED) {
+        if (want_M) {                                     // (a register array cannot be indexed by the run-time joint number)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { s1 += Pj[6 + k] * Pa[12 + k]; s2 += Pj[k] * Pa[18 + k]; s3 += Pj[6 + k] * Ja[k]; s4 += Pj[k] * Pa[12 + k]; }
-      s_T[j * W2 + a] = -s1 + s2;
-      s_T[j * W2 + N + a] = s3 - 2.0 * s4;
+          for (int k = 0; k < NJ; ++k) arow[k] = (k == i) ? sm : arow[k];
+        }
+      } else {
+        if (want_M) { Mo[i + (int64_t)j * N] = sm; Mo[j + (int64_t)i * N] = sm; }
+      }
+      if (i != j) {                                       // a proper ancestor of j: its u | g
+        double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double pa = wi[18 + k]; s1 += Pr[6 + k] * pa; s2 += Pr[k] * wi[24 + k]; s3 += Pr[6 + k] * Jr[k]; s4 += Pr[k] * pa; }
+        s_T[j * W2 + i] = -s1 + s2;
+        s_T[j * W2 + N + i] = s3 - 2.0 * s4;
+      }
     }
   }
   __syncthreads();
-  double* To = ap.Tws + (sbt * (2 * N + 1) + pp) * (int64_t)N * W2;
-  for (int k = lane; k < N * W2; k += AW) To[k] = s_T[k];
+  CLK(7);
+  if constexpr (!FUSED) {
+    double* To = ap.Tws + (sbt * (2 * N + 1) + pp) * (int64_t)N * W2;
+    for (int k = lane; k < N * W2; k += AW) To[k] = s_T[k];
+    CLK(8);
+  } else {
+    // ---- M^-1 of this evaluation's configuration into LDS (AnaLds::X) ----
+    double* s_Mi = lds + LY::X;                           // M^-1, column r at r * nv
+    const int n = 2 * N;
+    // the resident jacobians the slabs are differenced against: read now, used after the factorisation
+    constexpr bool PRE = NJ <= 40;
+    constexpr int RTM = (NJ + 15) / 16, KSM = (NJ + 3) / 4, JTM = (2 * NJ + 15) / 16, FBN = (NJ * NJ + AW - 1) / AW;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const bool diff = pp > 0 && ap.write_f;
+    double* fx = p.fx + bt * (int64_t)n * n;
+    double* fu = p.fu + bt * (int64_t)n * N;
+    double base[PRE ? JTM : 1][RTM][4], fb[PRE ? FBN : 1];
+    const int step_i = AW % N, step_j = AW / N;           // (i, j) of entry k + 64 from (i, j) of entry k, k = i + j nv
+    if constexpr (PRE) {
+#pragma unroll
+      for (int jt = 0; jt < JTM; ++jt)
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = 16 * jt + l4 + 4 * q, r = 16 * rt + l15;
+            const bool ok = diff && j < W2 && r < N;
+            base[jt][rt][q] = fx[ok ? (N + r) + j * n : 0];
+          }
+      int fi = lane % N, fj = lane / N;                   // entry lane + 64 u of the lower nv x nv block of f_u, without a division per entry
+#pragma unroll
+      for (int u = 0; u < FBN; ++u) {
+        const bool ok = diff && pp <= N && fj < N;
+        fb[u] = fu[ok ? N + fi + fj * n : 0];
+        fi += step_i; fj += step_j;
+        if (fi >= N) { fi -= N; ++fj; }
+      }
+    }
+    if (want_M) {
+      const int r = lane;
+      // M padded to NJ x NJ by an identity block: the arithmetic on the leading nv x nv block is unchanged (the padding only ever
+      // contributes exact zeros) and the factorisation is free of run-time guards
+      if (r >= N && r < NJ) {
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) arow[k] = (k == r) ? 1.0 : 0.0;
+      }
+      double x[NJ];
+      wave_spd_inverse<NJ>(arow, x, r);
+      double* Mg = ap.Fws ? ap.Mws + (sbt * (N + 1) + pp) * (int64_t)N * N : nullptr;   // the constraint chain reads M^-1(q') (ana_eq_kernel)
+      double* M0g = (ap.stage == 0 && ap.M0) ? ap.M0 + bt * (int64_t)N * N : nullptr;
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+          if (i < N) {
+            s_Mi[i + r * N] = x[i];                       // column r of M^-1
+            if (Mg) Mg[i + (int64_t)r * N] = x[i];
+            if (M0g) M0g[i + (int64_t)r * N] = x[i];
+          }
+      }
+    } else {
+      const double* M0g = ap.M0 + bt * (int64_t)N * N;    // a v direction: the trajectory point's M^-1
+      double* Mg = (ap.Fws && pp == N + 1) ? ap.Mws + (sbt * (N + 1)) * (int64_t)N * N : nullptr;   // ... which ana_eq_kernel expects in slot 0
+      for (int k = lane; k < N * N; k += AW) { const double vq = M0g[k]; s_Mi[k] = vq; if (Mg) Mg[k] = vq; }
+    }
+    __syncthreads();
+    CLK(8);
+    if (ap.stage == 0 && ap.m0_only) return;
+    // ---- R = -M^-1 T on the matrix cores, then the outputs (the split path's ana_out_kernel, operands in LDS) ----
+    typedef double f64x4_ __attribute__((ext_vector_type(4)));
+    double dt = m.dt;
+    const double eps = sqrt(DBL_EPSILON);
+    // every global read this wave still has in flight lands here, before the first store: the stores below then never sit
+    // behind a wait (the counter that guards a pending read also counts the stores issued since)
+    value_fence(dt);
+    if constexpr (PRE) {
+#pragma unroll
+      for (int jt = 0; jt < JTM; ++jt)
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) value_fence(base[jt][rt][q]);
+#pragma unroll
+      for (int u = 0; u < FBN; ++u) value_fence(fb[u]);
+    }
+    double* slab_xx = pp > 0 ? p.fxx + (bt * n + (pp - 1)) * (int64_t)n * n : nullptr;   // f_xx(:, :, p-1): n x n
+    double* slab_ux = pp > 0 ? p.fux + (bt * n + (pp - 1)) * (int64_t)n * N : nullptr;   // f_ux(:, :, p-1): n x nv
+    // D'(j, r) = sum_l T(l, j) Minv(l, r): A(row = j, k = l) = T(l, j), B(k = l, col = r) = Minv(l, r); tiles 16 x 16, k by 4.
+    // Result register q of a lane: D'(row = 16 jt + l4 + 4 q, col = 16 rt + l15)
+    const int JT = (W2 + 15) / 16;
+#pragma unroll
+    for (int jt = 0; jt < JTM; ++jt) {
+      if (jt >= JT) continue;
+      const int ja = 16 * jt + l15;
+      double bl[RTM][4];
+#pragma unroll
+      for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if constexpr (PRE) bl[rt][q] = base[jt][rt][q];
+          else {
+            const int j = 16 * jt + l4 + 4 * q, r = 16 * rt + l15;
+            const bool ok = diff && j < W2 && r < N;
+            bl[rt][q] = fx[ok ? (N + r) + j * n : 0];
+          }
+        }
+      double av[KSM];                                       // operands in batches: one LDS wait per batch (see batch_fence)
+#pragma unroll
+      for (int sk = 0; sk < KSM; ++sk) {
+        const int l = 4 * sk + l4;
+        av[sk] = s_T[(ja < W2 && l < N) ? l * W2 + ja : 0];
+      }
+#pragma unroll
+      for (int sk = 0; sk < KSM; ++sk) value_fence(av[sk]);
+      batch_fence();
+#pragma unroll
+      for (int sk = 0; sk < KSM; ++sk) av[sk] = (ja < W2 && 4 * sk + l4 < N) ? av[sk] : 0.0;
+#pragma unroll
+      for (int rt = 0; rt < RTM; ++rt) {
+        const int rb = 16 * rt + l15;
+        if (16 * rt >= N) continue;
+        double bv[KSM];
+#pragma unroll
+        for (int sk = 0; sk < KSM; ++sk) {
+          const int l = 4 * sk + l4;
+          bv[sk] = s_Mi[(rb < N && l < N) ? l + rb * N : 0];
+        }
+#pragma unroll
+        for (int sk = 0; sk < KSM; ++sk) value_fence(bv[sk]);
+        batch_fence();
+#pragma unroll
+        for (int sk = 0; sk < KSM; ++sk) bv[sk] = (rb < N && 4 * sk + l4 < N) ? bv[sk] : 0.0;
+        f64x4_ acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sk = 0; sk < KSM; ++sk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sk], bv[sk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = 16 * jt + l4 + 4 * q;             // column of the jacobian block (0 .. 2nv-1: q then v directions)
+          const int r = rb;                               // row (joint)
+          if (j >= W2 || r >= N) continue;
+          double val = (-acc[q]) * dt;                    // first_order_deriv, problem.hpp:499-501
+          if (j >= N && j - N == r) val = val + 1.0;
+          const int off = (N + r) + j * n;
+          if (pp == 0) fx[off] = val;
+          else {
+            if (ap.write_f) slab_xx[off] = (val - bl[rt][q]) / eps;          // problem.hpp:128-137
+            if (ap.Fws) ap.Fws[(sbt * (2 * N) + (pp - 1)) * (int64_t)N * n + r + (int64_t)j * N] = val;
+          }
+        }
+      }
+    }
+    if (pp == 0 || ap.write_f) {
+      // the rows of q+ = q + dt v: constants (problem.hpp:487-490), so their differences are exact zeros
+      {
+        int i = lane % N, j = lane / N;
+        for (; j < n; ) {
+          const int off = i + j * n;
+          if (pp == 0) fx[off] = (j == i) ? 1.0 : ((j == N + i) ? 1.0 * dt : 0.0);
+          else slab_xx[off] = 0.0;
+          i += step_i; j += step_j;
+          if (i >= N) { i -= N; ++j; }
+        }
+      }
+      // f_u = [0; dt M^-1] (problem.hpp:493,502): n x nv, the upper nv rows zero; entry idx = i + j nv of the lower block
+      {
+        int i = lane % N, j = lane / N, idx = lane;
+#pragma unroll
+        for (int u = 0; u < FBN; ++u) {
+          if (j < N) {
+            const int off = i + j * n;
+            if (pp == 0) { fu[off] = 0.0; fu[N + off] = s_Mi[idx] * dt; }
+            else {
+              slab_ux[off] = 0.0;
+              if (pp <= N) {
+                double fbv;
+                if constexpr (PRE) fbv = fb[u]; else fbv = fu[N + off];
+                slab_ux[N + off] = (s_Mi[idx] * dt - fbv) / eps;             // problem.hpp:138-140
+              } else slab_ux[N + off] = 0.0;              // a v direction: the same M^-1, fu_ == fu
+            }
+          }
+          i += step_i; j += step_j; idx += AW;
+          if (i >= N) { i -= N; ++j; }
+        }
+      }
+    }
+    CLK(9);
+  }
+#ifdef DEV_ANA_CLOCKS
+  if (lane == 0 && ap.stage == 1 && (e == 5 * P + 3 || e == 17 * P + 50 || e == 100 * P + 1))
+    printf("ana_eval pp=%d: setup %llu aba/load %llu levels %llu body1 %llu composite %llu body2 %llu zero %llu assemble %llu store/minv %llu out %llu total %llu\n", pp,
+           clk[1] - clk[0], 0ull, clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3], clk[5] - clk[4], clk[6] - clk[5], clk[7] - clk[6], clk[8] - clk[7], clk[9] - clk[8], (FUSED ? clk[9] : clk[8]) - clk[0]);
+#endif
 }
 
 // ---- kernel B: M -> M^-1 (in place in the workspace); lane = row / right-hand side ------------------------------------
@@ -502,8 +840,7 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
   const Dims& d = ctx->d;
   const int64_t BT = d.batch * d.T;
   const int N = (int)d.nv;
-  constexpr int R1 = 78 * NJ > rbd::ABA_LDS_SLOTS * NJ ? 78 * NJ : rbd::ABA_LDS_SLOTS * NJ;
-  const size_t lds = sizeof(double) * (size_t)(R1 + 30 * NJ + 36 * NJ + 4 * NJ);
+  const size_t lds = sizeof(double) * (size_t)AnaLds<NJ>::TOTAL;
   const bool do_f = (flags & ANA_F) != 0;
   const bool do_eq = (flags & ANA_EQ) != 0 && d.Etot > 0;
   AnaParams ap{};
@@ -537,11 +874,38 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
     HIP_TRY(hipGetLastError());
     return DDP_HIP_OK;
   }
+  if (!ctx->ana_split) {
+    // fused path: one wave takes an evaluation from the state to its output columns; no T / M workspace
+    ap.M0 = ctx->ana_M0;
+    if (stage == 0) {
+      ap.bt0 = 0; ap.nbt = (int32_t)BT;
+      hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)BT), dim3(AW), lds, ctx->stream, ap);
+      if (do_eq) hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)BT), dim3(AW), eq_lds_bytes<NJ>(d), ctx->stream, ap);
+      HIP_TRY(hipGetLastError());
+      return DDP_HIP_OK;
+    }
+    if (!ctx->ana_M0) return DDP_HIP_E_UNSUPPORTED;
+    {                                                     // M^-1 at the trajectory points, for the v directions
+      AnaParams a0 = ap;
+      a0.stage = 0; a0.m0_only = 1; a0.bt0 = 0; a0.nbt = (int32_t)BT; a0.Fws = nullptr; a0.accel = nullptr;
+      hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)BT), dim3(AW), lds, ctx->stream, a0);
+    }
+    const int64_t step = do_eq ? ctx->ana_nbt : BT;       // the constraint chain reads per-slice workspaces (Fws, Mws)
+    for (int64_t bt0 = 0; bt0 < BT; bt0 += step) {
+      const int64_t nb = BT - bt0 < step ? BT - bt0 : step;
+      ap.bt0 = bt0;
+      ap.nbt = (int32_t)nb;
+      hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)(nb * 2 * N)), dim3(AW), lds, ctx->stream, ap);
+      if (do_eq) hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)(nb * 3 * N)), dim3(AW), eq_lds_bytes<NJ>(d), ctx->stream, ap);
+    }
+    HIP_TRY(hipGetLastError());
+    return DDP_HIP_OK;
+  }
   for (int64_t bt0 = 0; bt0 < BT; bt0 += ctx->ana_nbt) {
     const int64_t nb = BT - bt0 < ctx->ana_nbt ? BT - bt0 : ctx->ana_nbt;
     ap.bt0 = bt0;
     ap.nbt = (int32_t)nb;
-    hipLaunchKernelGGL((ana_eval_kernel<NJ>), dim3((unsigned)(nb * P)), dim3(AW), lds, ctx->stream, ap);
+    hipLaunchKernelGGL((ana_eval_kernel<NJ, false>), dim3((unsigned)(nb * P)), dim3(AW), lds, ctx->stream, ap);
     hipLaunchKernelGGL((ana_minv_kernel<NJ>), dim3((unsigned)(nb * C)), dim3(AW), 0, ctx->stream, ap);
     hipLaunchKernelGGL((ana_out_kernel<NJ>), dim3((unsigned)(nb * P)), dim3(AW), 0, ctx->stream, ap);
     if (do_eq)
@@ -563,8 +927,11 @@ int lin_analytic_setup(ddp_hip_ctx* ctx) {
   ctx->ana_nbt = BT < slice ? BT : slice;
   const int64_t N = d.nv;
   // the stage-0 and stage-1 launches of one linearisation share the workspace: the base point keeps slot 0 of every pair
-  HIP_TRY(hipMalloc(&ctx->ana_T, sizeof(double) * (size_t)(ctx->ana_nbt * (2 * N + 1) * N * 2 * N)));
-  HIP_TRY(hipMalloc(&ctx->ana_M, sizeof(double) * (size_t)(ctx->ana_nbt * (N + 1) * N * N)));
+  ctx->ana_split = getenv("DDP_HIP_ANA_SPLIT") != nullptr;    // development: the three-kernel form with its HBM workspaces
+  const bool m1 = ctx->model_h.fd_mode == 1 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS);
+  if (ctx->ana_split) HIP_TRY(hipMalloc(&ctx->ana_T, sizeof(double) * (size_t)(ctx->ana_nbt * (2 * N + 1) * N * 2 * N)));
+  if (ctx->ana_split || (m1 && d.Etot > 0)) HIP_TRY(hipMalloc(&ctx->ana_M, sizeof(double) * (size_t)(ctx->ana_nbt * (N + 1) * N * N)));
+  if (!ctx->ana_split && m1) HIP_TRY(hipMalloc(&ctx->ana_M0, sizeof(double) * (size_t)(BT * N * N)));
   if (ctx->lin_static && ctx->lin_ws && ctx->model_h.fd_mode == 1 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS))
     HIP_TRY(hipMalloc(&ctx->ana_A, sizeof(double) * (size_t)(BT * 2 * N * N)));
   if (d.Etot > 0) {
@@ -576,11 +943,10 @@ int lin_analytic_setup(ddp_hip_ctx* ctx) {
     if (l38 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ana_eq_kernel<38>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l38));
     if (d.nv > 38 && l64 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ana_eq_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l64));
   }
-  constexpr int NJ = 64;
-  constexpr int R1 = 78 * NJ > rbd::ABA_LDS_SLOTS * NJ ? 78 * NJ : rbd::ABA_LDS_SLOTS * NJ;
   if (d.nv > 38) {
-    const size_t lds = sizeof(double) * (size_t)(R1 + 30 * NJ + 36 * NJ + 4 * NJ);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ana_eval_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = sizeof(double) * (size_t)AnaLds<64>::TOTAL;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ana_eval_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ana_eval_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   return DDP_HIP_OK;
 }
@@ -590,10 +956,11 @@ void lin_analytic_teardown(ddp_hip_ctx* ctx) {
   if (ctx->ana_M) (void)hipFree(ctx->ana_M);
   if (ctx->ana_F) (void)hipFree(ctx->ana_F);
   if (ctx->ana_A) (void)hipFree(ctx->ana_A);
+  if (ctx->ana_M0) (void)hipFree(ctx->ana_M0);
 }
 
 int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
-  if (!ctx->ana_T || !ctx->ana_M) return DDP_HIP_E_UNSUPPORTED;
+  if (ctx->ana_nbt <= 0) return DDP_HIP_E_UNSUPPORTED;   // lin_analytic_setup did not take this model
   if (stage == 1 && !p.has_tensors) return DDP_HIP_OK;
   if (ctx->d.nv <= 38) return launch_t<38>(ctx, p, stage, flags);
   return launch_t<64>(ctx, p, stage, flags);
