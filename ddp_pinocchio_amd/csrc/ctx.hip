@@ -348,7 +348,7 @@ extern "C" int64_t ddp_hip_seq_size(const ddp_hip_ctx* ctx, int seq) {
 
 extern "C" double* ddp_hip_device_ptr(ddp_hip_ctx* ctx, int seq) {
   if (!ctx || seq < 0 || seq >= DDP_HIP_SEQ_COUNT) return nullptr;
-  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUX || seq == DDP_HIP_SEQ_FUU) { ctx->tensor_tops_zero = false; ctx->tensor_tops_sparse = false; }
+  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUX || seq == DDP_HIP_SEQ_FUU) { ctx->tensor_tops_zero = false; ctx->tensor_tops_sparse = false; ctx->fuu_zero = false; }
   if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUU) {
     (void)hipSetDevice(ctx->device);
     if (lin_materialize_fxx(ctx) != DDP_HIP_OK) return nullptr;
@@ -371,7 +371,7 @@ extern "C" int ddp_hip_upload(ddp_hip_ctx* ctx, int seq, const double* host, int
   if (sz == 0 || count == 0) return DDP_HIP_OK;
   if (!host) return DDP_HIP_E_ARG;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUX || seq == DDP_HIP_SEQ_FUU) { ctx->tensor_tops_zero = false; ctx->tensor_tops_sparse = false; }
+  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUX || seq == DDP_HIP_SEQ_FUU) { ctx->tensor_tops_zero = false; ctx->tensor_tops_sparse = false; ctx->fuu_zero = false; }
   if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUU) {   // tensors from outside: no symmetry assumed (bwd_split.h)
     { const int rc_ = lin_materialize_fxx(ctx); if (rc_ != DDP_HIP_OK) return rc_; }   // what is not overwritten (other instances, the other tensor) stays whole
     ctx->tensors_sym = false;
@@ -398,7 +398,7 @@ extern "C" int ddp_hip_fill(ddp_hip_ctx* ctx, int seq, double value) {
   int rc = check_range(ctx, seq, 0, 0);
   if (rc != DDP_HIP_OK) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUX || seq == DDP_HIP_SEQ_FUU) { ctx->tensor_tops_zero = false; ctx->tensor_tops_sparse = false; }
+  if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUX || seq == DDP_HIP_SEQ_FUU) { ctx->tensor_tops_zero = false; ctx->tensor_tops_sparse = false; ctx->fuu_zero = false; }
   if (seq == DDP_HIP_SEQ_FXX || seq == DDP_HIP_SEQ_FUU) {
     const int rc_ = lin_materialize_fxx(ctx);
     if (rc_ != DDP_HIP_OK) return rc_;

@@ -18,6 +18,7 @@
 //                     eq_xx, eq_ux, eq_uu (problem.hpp:67-150 with Fn = the constraint chain, :611-620)
 #include <float.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <utility>
 
@@ -69,6 +70,11 @@ template <int NJ> struct AnaLds {
 // arithmetic on a batch is not sunk below the next one: one wait per batch and a bounded number of registers in flight.
 __device__ __forceinline__ void batch_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void value_fence(double& v) { asm volatile("" : "+v"(v)); }
+// ana_eval_kernel's work-group is ONE wave (AW = 64), and the LDS executes a wave's accesses in program order: a value one lane
+// wrote is there for any lane's later read without s_barrier.  What is left of a barrier is the compiler-level ordering -- and,
+// unlike __syncthreads, no wait for the global reads the wave has in flight (the prefetched jacobians)
+static_assert(AW == 64, "wave_sync assumes a one-wave work-group");
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
 // the value lane `src` (a constant) holds, as a wave-uniform scalar: two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double lane_bcast(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -156,7 +162,6 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
   double* s_tau = s_v + NJ;
   double* s_a = s_tau + NJ;
   int* s_par = reinterpret_cast<int*>(s_a + NJ);   // parent of joint i
-  int* s_lvl = s_par + NJ;                         // tree depth of joint i
 
   // lane i owns joint i (nv <= 64): its constants, its state and its own placement stay in registers, so the model table is read
   // once, by all lanes at the same time, and the level loop below touches nothing but LDS
@@ -182,97 +187,106 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
       for (int l = 0; l < 3; ++l) Rl[3 * k + l] = E[3 * l + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) ax[k] = m.axis[ji][k];
-    if (live) {                                           // depth of joint lvl_joint[lane]: the levels that end at or before its slot
-      int lv = 0;
-      for (int L = 1; L < m.n_levels; ++L) lv += (lane >= m.lvl_start[L]) ? 1 : 0;
-      s_lvl[m.lvl_joint[lane]] = lv;
+    if (live) {                                           // the joint's own placement, for its descendants' walks
+      double* w = s_W + 30 * lane;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) w[k] = Rl[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w[9 + k] = rl[k];
     }
   }
-  __syncthreads();
+  wave_sync();
   if (ap.accel != nullptr && pp >= 1) {
     const double* __restrict__ ag = ap.accel + ((int64_t)bt * W2 + (pp - 1)) * N;
     if (live) s_a[lane] = ag[lane];
   } else {
     rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_R1, 0, lane, true);   // ends with a barrier
   }
-  const int my_lvl = live ? s_lvl[lane] : -1;
-  __syncthreads();
+  wave_sync();
   const double ai = live ? s_a[lane] : 0.0;
   CLK(1);
-  // world-frame recursion, root -> leaves: the joints of one level in parallel
-  for (int L = 0; L < m.n_levels; ++L) {
-    if (my_lvl == L) {
-      double oR[9], op[3], J[6], ov[6], oa[6];
-      const double* wp = s_W + 30 * (par_i >= 0 ? par_i : 0);
-      if (par_i >= 0) {
-        double oRp[9], t3[3];
+  // world-frame kinematics.  Every joint walks its own path to the root -- all lanes at once, three barriers in all -- instead of
+  // the tree being swept level by level (one barrier per level, a handful of lanes busy): placement as the product of the joint
+  // placements along the path, velocity and acceleration as path sums of per-joint terms.
+  double oR[9], op[3], J[6], ov[6], oa[6];
+  {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) oRp[k] = wp[k];
-        rbd::mm3(oRp, Rl, oR);
-        rbd::mv3(oRp, rl, t3);
+    for (int k = 0; k < 9; ++k) oR[k] = Rl[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) op[k] = wp[9 + k] + t3[k];
-      } else {
+    for (int k = 0; k < 3; ++k) op[k] = rl[k];
+    for (int a = live ? par_i : -1; a >= 0; a = s_par[a]) {   // oX_i = oX_a aX_i: rotation R_a R, translation r_a + R_a p
+      const double* wa = s_W + 30 * a;
+      double Ra[9], t9[9], t3[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) oR[k] = Rl[k];
+      for (int k = 0; k < 9; ++k) Ra[k] = wa[k];
+      rbd::mm3(Ra, oR, t9);
+      rbd::mv3(Ra, op, t3);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) op[k] = rl[k];
-      }
-      {                                                   // rbdd::world_axis
-        double aw[3];
-        rbd::mv3(oR, ax, aw);
-        if (revolute) {
-          double t3[3];
-          rbd::cross3(op, aw, t3);
-          J[0] = aw[0]; J[1] = aw[1]; J[2] = aw[2]; J[3] = t3[0]; J[4] = t3[1]; J[5] = t3[2];
-        } else {
-          J[0] = 0.0; J[1] = 0.0; J[2] = 0.0; J[3] = aw[0]; J[4] = aw[1]; J[5] = aw[2];
-        }
-      }
-      double vJ[6], t6[6];
+      for (int k = 0; k < 9; ++k) oR[k] = t9[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vJ[k] = J[k] * vi;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ov[k] = (par_i >= 0 ? wp[18 + k] : 0.0) + vJ[k];
-      rbd::crm(ov, vJ, t6);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double apk = par_i >= 0 ? wp[24 + k] : (k < 3 ? 0.0 : -m.gravity[k - 3]);
-        oa[k] = apk + J[k] * ai + t6[k];
-      }
-      double* w = s_W + 30 * lane;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) w[k] = oR[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) w[9 + k] = op[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { w[12 + k] = J[k]; w[18 + k] = ov[k]; w[24 + k] = oa[k]; }
+      for (int k = 0; k < 3; ++k) op[k] = wa[9 + k] + t3[k];
     }
-    __syncthreads();
+    double aw[3];                                         // rbdd::world_axis
+    rbd::mv3(oR, ax, aw);
+    if (revolute) {
+      double t3[3];
+      rbd::cross3(op, aw, t3);
+      J[0] = aw[0]; J[1] = aw[1]; J[2] = aw[2]; J[3] = t3[0]; J[4] = t3[1]; J[5] = t3[2];
+    } else {
+      J[0] = 0.0; J[1] = 0.0; J[2] = 0.0; J[3] = aw[0]; J[4] = aw[1]; J[5] = aw[2];
+    }
   }
+  double vJ[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vJ[k] = J[k] * vi;
+  if (live) {
+    double* w = s_W + 30 * lane;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { w[12 + k] = J[k]; w[18 + k] = vJ[k]; }
+  }
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ov[k] = vJ[k];
+  for (int a = live ? par_i : -1; a >= 0; a = s_par[a]) {     // ov_i = sum over the path of J_a v_a
+    const double* wa = s_W + 30 * a + 18;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ov[k] += wa[k];
+  }
+  {
+    double t6[6];
+    rbd::crm(ov, vJ, t6);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) oa[k] = J[k] * ai + t6[k];   // the joint's own term of the acceleration sum
+    if (live) {
+      double* w = s_W + 30 * lane + 24;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[k] = oa[k];
+    }
+  }
+  wave_sync();
+  for (int a = live ? par_i : -1; a >= 0; a = s_par[a]) {     // oa_i = -g + sum over the path of J_a qdd_a + ov_a x J_a v_a
+    const double* wa = s_W + 30 * a + 24;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) oa[k] += wa[k];
+  }
+#pragma unroll
+  for (int k = 3; k < 6; ++k) oa[k] -= m.gravity[k - 3];
   CLK(2);
   // per body: world inertia, force, bias matrix (the ABA state in s_R1 is dead)
-  for (int i = lane; i < N; i += AW) {
-    const double* w = s_W + 30 * i;
-    double oR[9], op[3], ov[6], oa[6], I6[36], B[36], h[6], Ioa[6], vxh[6];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) oR[k] = w[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) op[k] = w[9 + k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { ov[k] = w[18 + k]; oa[k] = w[24 + k]; }
-    rbdd::world_inertia(m.I6[i], oR, op, I6);
+  if (live) {
+    double I6[36], B[36], h[6], Ioa[6], vxh[6];
+    rbdd::world_inertia(m.I6[lane], oR, op, I6);
     rbdd::m6v(I6, ov, h);
     rbdd::m6v(I6, oa, Ioa);
     rbd::crf(ov, h, vxh);
     rbdd::bias_matrix(I6, ov, h, B);
-    double* o = s_R1 + 78 * i;
+    double* o = s_R1 + 78 * lane;
 #pragma unroll
     for (int k = 0; k < 36; ++k) { o[k] = I6[k]; o[36 + k] = B[k]; }
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[72 + k] = Ioa[k] + vxh[k];
   }
-  __syncthreads();
+  wave_sync();
   CLK(3);
   // composite sums leaves -> root: lane l < 39 owns entries 2l, 2l+1 of every record (a lane only ever touches its own entries,
   // and the LDS executes a wave's accesses in order); children precede parents in this descending sweep
@@ -286,15 +300,15 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
       *dst = *dst + c;
     }
   }
-  __syncthreads();
+  wave_sync();
   CLK(4);
   double Pr[36];                                          // y | z | u | g | Fq | Fv of the lane's joint; the others read its u | g from s_W
   if (live) {
     double* w = s_W + 30 * lane;
     const double* c = s_R1 + 78 * lane;
-    double J[6], ov[6], oa[6], Ic[36], Bc[36], ofc[6];
+    double Ic[36], Bc[36], ofc[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { J[k] = w[12 + k]; ov[k] = w[18 + k]; oa[k] = w[24 + k]; ofc[k] = c[72 + k]; }
+    for (int k = 0; k < 6; ++k) ofc[k] = c[72 + k];
 #pragma unroll
     for (int k = 0; k < 36; ++k) { Ic[k] = c[k]; Bc[k] = c[36 + k]; }
     double t1[6], t2[6], t3[6];
@@ -317,18 +331,53 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) Pr[30 + k] = t1[k] - 2.0 * t2[k];
   }
-  __syncthreads();
+  wave_sync();
   CLK(5);
+  // fused path: the resident jacobians the slabs are differenced against, and (a v direction) the trajectory point's M^-1 -- read
+  // now, used after the factorisation: the latency of these reads hides behind the dynamics
+  const int n = 2 * N;
+  constexpr bool PRE = FUSED && NJ <= 40;
+  constexpr int RTM = (NJ + 15) / 16, KSM = (NJ + 3) / 4, JTM = (2 * NJ + 15) / 16, FBN = (NJ * NJ + AW - 1) / AW;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool diff = pp > 0 && ap.write_f;
+  const bool want_M = pp <= N;
+  double* fx = p.fx + bt * (int64_t)n * n;
+  double* fu = p.fu + bt * (int64_t)n * N;
+  double base[PRE ? JTM : 1][RTM][4], fb[PRE ? FBN : 1];   // fb: f_u's lower block (a q direction) or M^-1 of the trajectory point (a v direction)
+  const int step_i = AW % N, step_j = AW / N;             // (i, j) of entry k + 64 from (i, j) of entry k, k = i + j nv
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int jt = 0; jt < JTM; ++jt)
+#pragma unroll
+      for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = 16 * jt + l4 + 4 * q, r = 16 * rt + l15;
+          const bool ok = diff && j < W2 && r < N;
+          base[jt][rt][q] = fx[ok ? (N + r) + j * n : 0];
+        }
+    int fi = lane % N, fj = lane / N;                     // entry lane + 64 u of the lower nv x nv block of f_u, without a division per entry
+    const double* fbp = want_M ? fu : ap.M0 + bt * (int64_t)N * N;
+#pragma unroll
+    for (int u = 0; u < FBN; ++u) {
+      const bool ok = want_M ? (diff && fj < N) : (lane + u * AW < N * N);
+      fb[u] = fbp[ok ? (want_M ? N + fi + fj * n : lane + u * AW) : 0];
+      fi += step_i; fj += step_j;
+      if (fi >= N) { fi -= N; ++fj; }
+    }
+  };
+  // (a v direction has nothing but these reads between the assembly and its products; a q direction has the factorisation, and is
+  // better off issuing them there than holding 2 x 83 registers through the assembly)
+  if constexpr (PRE) { if (!want_M) prefetch(); }
   // T (row-major nv x 2nv: [d tau/dq | d tau/dv]) in LDS over the dead composite region, M straight to the workspace
   double* s_T = lds + LY::T;
   for (int k = lane; k < N * W2; k += AW) s_T[k] = 0.0;
-  __syncthreads();
-  const bool want_M = pp <= N;
+  wave_sync();
   double* Mo = ap.Mws + (sbt * (N + 1) + (want_M ? pp : 0)) * (int64_t)N * N;
   if constexpr (!FUSED) {
     if (want_M)
       for (int k = lane; k < N * N; k += AW) Mo[k] = 0.0;
-    __syncthreads();
+    wave_sync();
   }
   double arow[FUSED ? NJ : 1];                            // fused path: row `lane` of the lower triangle of M (its nonzeros lie on the lane's path)
   if constexpr (FUSED) {
@@ -365,7 +414,7 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
       }
     }
   }
-  __syncthreads();
+  wave_sync();
   CLK(7);
   if constexpr (!FUSED) {
     double* To = ap.Tws + (sbt * (2 * N + 1) + pp) * (int64_t)N * W2;
@@ -374,36 +423,7 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
   } else {
     // ---- M^-1 of this evaluation's configuration into LDS (AnaLds::X) ----
     double* s_Mi = lds + LY::X;                           // M^-1, column r at r * nv
-    const int n = 2 * N;
-    // the resident jacobians the slabs are differenced against: read now, used after the factorisation
-    constexpr bool PRE = NJ <= 40;
-    constexpr int RTM = (NJ + 15) / 16, KSM = (NJ + 3) / 4, JTM = (2 * NJ + 15) / 16, FBN = (NJ * NJ + AW - 1) / AW;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const bool diff = pp > 0 && ap.write_f;
-    double* fx = p.fx + bt * (int64_t)n * n;
-    double* fu = p.fu + bt * (int64_t)n * N;
-    double base[PRE ? JTM : 1][RTM][4], fb[PRE ? FBN : 1];
-    const int step_i = AW % N, step_j = AW / N;           // (i, j) of entry k + 64 from (i, j) of entry k, k = i + j nv
-    if constexpr (PRE) {
-#pragma unroll
-      for (int jt = 0; jt < JTM; ++jt)
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = 16 * jt + l4 + 4 * q, r = 16 * rt + l15;
-            const bool ok = diff && j < W2 && r < N;
-            base[jt][rt][q] = fx[ok ? (N + r) + j * n : 0];
-          }
-      int fi = lane % N, fj = lane / N;                   // entry lane + 64 u of the lower nv x nv block of f_u, without a division per entry
-#pragma unroll
-      for (int u = 0; u < FBN; ++u) {
-        const bool ok = diff && pp <= N && fj < N;
-        fb[u] = fu[ok ? N + fi + fj * n : 0];
-        fi += step_i; fj += step_j;
-        if (fi >= N) { fi -= N; ++fj; }
-      }
-    }
+    if constexpr (PRE) { if (want_M) prefetch(); }
     if (want_M) {
       const int r = lane;
       // M padded to NJ x NJ by an identity block: the arithmetic on the leading nv x nv block is unchanged (the padding only ever
@@ -428,9 +448,17 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     } else {
       const double* M0g = ap.M0 + bt * (int64_t)N * N;    // a v direction: the trajectory point's M^-1
       double* Mg = (ap.Fws && pp == N + 1) ? ap.Mws + (sbt * (N + 1)) * (int64_t)N * N : nullptr;   // ... which ana_eq_kernel expects in slot 0
-      for (int k = lane; k < N * N; k += AW) { const double vq = M0g[k]; s_Mi[k] = vq; if (Mg) Mg[k] = vq; }
+      if constexpr (PRE) {
+#pragma unroll
+        for (int u = 0; u < FBN; ++u) {
+          const int k = lane + u * AW;
+          if (k < N * N) { s_Mi[k] = fb[u]; if (Mg) Mg[k] = fb[u]; }
+        }
+      } else {
+        for (int k = lane; k < N * N; k += AW) { const double vq = M0g[k]; s_Mi[k] = vq; if (Mg) Mg[k] = vq; }
+      }
     }
-    __syncthreads();
+    wave_sync();
     CLK(8);
     if (ap.stage == 0 && ap.m0_only) return;
     // ---- R = -M^-1 T on the matrix cores, then the outputs (the split path's ana_out_kernel, operands in LDS) ----
@@ -455,72 +483,95 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     // D'(j, r) = sum_l T(l, j) Minv(l, r): A(row = j, k = l) = T(l, j), B(k = l, col = r) = Minv(l, r); tiles 16 x 16, k by 4.
     // Result register q of a lane: D'(row = 16 jt + l4 + 4 q, col = 16 rt + l15)
     const int JT = (W2 + 15) / 16;
+    // the destination of a result is wave-uniform (kind 0: the trajectory point's f_x; 1: its f_xx slab; 2: the workspace of the
+    // constraint chain alone; 3: both): one specialised copy of the loop per kind, so the loop body carries no uniform branches
+    double* fws = ap.Fws ? ap.Fws + (sbt * (2 * N) + (pp - 1)) * (int64_t)N * n : nullptr;
+    auto products = [&](auto kind_c) {
+      constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
-    for (int jt = 0; jt < JTM; ++jt) {
-      if (jt >= JT) continue;
-      const int ja = 16 * jt + l15;
-      double bl[RTM][4];
-#pragma unroll
-      for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if constexpr (PRE) bl[rt][q] = base[jt][rt][q];
-          else {
-            const int j = 16 * jt + l4 + 4 * q, r = 16 * rt + l15;
-            const bool ok = diff && j < W2 && r < N;
-            bl[rt][q] = fx[ok ? (N + r) + j * n : 0];
-          }
-        }
-      double av[KSM];                                       // operands in batches: one LDS wait per batch (see batch_fence)
-#pragma unroll
-      for (int sk = 0; sk < KSM; ++sk) {
-        const int l = 4 * sk + l4;
-        av[sk] = s_T[(ja < W2 && l < N) ? l * W2 + ja : 0];
-      }
-#pragma unroll
-      for (int sk = 0; sk < KSM; ++sk) value_fence(av[sk]);
-      batch_fence();
-#pragma unroll
-      for (int sk = 0; sk < KSM; ++sk) av[sk] = (ja < W2 && 4 * sk + l4 < N) ? av[sk] : 0.0;
-#pragma unroll
-      for (int rt = 0; rt < RTM; ++rt) {
-        const int rb = 16 * rt + l15;
-        if (16 * rt >= N) continue;
-        double bv[KSM];
+      for (int jt = 0; jt < JTM; ++jt) {
+        if (jt >= JT) continue;
+        const int ja = 16 * jt + l15;
+        // all operands of the jt-th row of tiles in one batch of LDS reads, then RTM independent accumulation chains: the matrix
+        // pipe (16 passes per v_mfma_f64_16x16x4) is the only thing this loop should wait for
+        double av[KSM], bv[RTM][KSM];
 #pragma unroll
         for (int sk = 0; sk < KSM; ++sk) {
           const int l = 4 * sk + l4;
-          bv[sk] = s_Mi[(rb < N && l < N) ? l + rb * N : 0];
+          av[sk] = s_T[(ja < W2 && l < N) ? l * W2 + ja : 0];
+#pragma unroll
+          for (int rt = 0; rt < RTM; ++rt) {
+            const int rb = 16 * rt + l15;
+            bv[rt][sk] = s_Mi[(rb < N && l < N) ? l + rb * N : 0];
+          }
         }
 #pragma unroll
-        for (int sk = 0; sk < KSM; ++sk) value_fence(bv[sk]);
+        for (int sk = 0; sk < KSM; ++sk) {
+          value_fence(av[sk]);
+#pragma unroll
+          for (int rt = 0; rt < RTM; ++rt) value_fence(bv[rt][sk]);
+        }
         batch_fence();
+        f64x4_ acc[RTM];
 #pragma unroll
-        for (int sk = 0; sk < KSM; ++sk) bv[sk] = (rb < N && 4 * sk + l4 < N) ? bv[sk] : 0.0;
-        f64x4_ acc = {0.0, 0.0, 0.0, 0.0};
+        for (int rt = 0; rt < RTM; ++rt) acc[rt] = f64x4_{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int sk = 0; sk < KSM; ++sk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sk], bv[sk], acc, 0, 0, 0);
+        for (int sk = 0; sk < KSM; ++sk) {
+          const bool lok = 4 * sk + l4 < N;
+          const double a_ = (ja < W2 && lok) ? av[sk] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = 16 * jt + l4 + 4 * q;             // column of the jacobian block (0 .. 2nv-1: q then v directions)
-          const int r = rb;                               // row (joint)
-          if (j >= W2 || r >= N) continue;
-          double val = (-acc[q]) * dt;                    // first_order_deriv, problem.hpp:499-501
-          if (j >= N && j - N == r) val = val + 1.0;
-          const int off = (N + r) + j * n;
-          if (pp == 0) fx[off] = val;
-          else {
-            if (ap.write_f) slab_xx[off] = (val - bl[rt][q]) / eps;          // problem.hpp:128-137
-            if (ap.Fws) ap.Fws[(sbt * (2 * N) + (pp - 1)) * (int64_t)N * n + r + (int64_t)j * N] = val;
+          for (int rt = 0; rt < RTM; ++rt) {
+            const double b_ = (16 * rt + l15 < N && lok) ? bv[rt][sk] : 0.0;
+            acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc[rt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = 16 * jt + l4 + 4 * q;           // column of the jacobian block (0 .. 2nv-1: q then v directions)
+            const int r = 16 * rt + l15;                  // row (joint)
+            double val = (-acc[rt][q]) * dt;              // first_order_deriv, problem.hpp:499-501
+            val = (j >= N && j - N == r) ? val + 1.0 : val;
+            value_fence(val);                             // the jacobian entry as the reference rounds it, before it is differenced (no fused multiply-subtract)
+            double bq;
+            if constexpr (PRE) bq = base[jt][rt][q];
+            else bq = (KIND == 1 || KIND == 3) ? fx[(j < W2 && r < N) ? (N + r) + j * n : 0] : 0.0;
+            if (j < W2 && r < N) {
+              const int off = (N + r) + j * n;
+              if constexpr (KIND == 0) fx[off] = val;
+              if constexpr (KIND == 1 || KIND == 3) slab_xx[off] = (val - bq) / eps;     // problem.hpp:128-137
+              if constexpr (KIND == 2 || KIND == 3) fws[r + j * N] = val;
+            }
           }
         }
       }
-    }
+    };
+    if (pp == 0) products(std::integral_constant<int, 0>{});
+    else if (ap.write_f && !fws) products(std::integral_constant<int, 1>{});
+    else if (ap.write_f) products(std::integral_constant<int, 3>{});
+    else if (fws) products(std::integral_constant<int, 2>{});
+    CLK(10);
     if (pp == 0 || ap.write_f) {
-      // the rows of q+ = q + dt v: constants (problem.hpp:487-490), so their differences are exact zeros
-      {
-        int i = lane % N, j = lane / N;
-        for (; j < n; ) {
+      // the rows of q+ = q + dt v are constants (problem.hpp:487-490), so their differences are exact zeros, and f_u = [0; dt M^-1]
+      // (problem.hpp:493,502) has its upper nv rows zero: with an even nv the zeros of a slab go out 16 bytes per lane
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const bool wide = pp > 0 && (N & 1) == 0 && ((reinterpret_cast<uintptr_t>(slab_xx) | reinterpret_cast<uintptr_t>(slab_ux)) & 15) == 0;
+      if (wide) {
+        const int H = N / 2, si = AW % H, sj = AW / H;
+        const d2 z2 = {0.0, 0.0};
+        for (int i = lane % H, j = lane / H; j < n; ) {
+          *reinterpret_cast<d2*>(slab_xx + 2 * i + j * n) = z2;
+          i += si; j += sj;
+          if (i >= H) { i -= H; ++j; }
+        }
+        for (int i = lane % H, j = lane / H; j < N; ) {
+          *reinterpret_cast<d2*>(slab_ux + 2 * i + j * n) = z2;
+          i += si; j += sj;
+          if (i >= H) { i -= H; ++j; }
+        }
+      } else {
+        for (int i = lane % N, j = lane / N; j < n; ) {
           const int off = i + j * n;
           if (pp == 0) fx[off] = (j == i) ? 1.0 : ((j == N + i) ? 1.0 * dt : 0.0);
           else slab_xx[off] = 0.0;
@@ -528,7 +579,8 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
           if (i >= N) { i -= N; ++j; }
         }
       }
-      // f_u = [0; dt M^-1] (problem.hpp:493,502): n x nv, the upper nv rows zero; entry idx = i + j nv of the lower block
+      CLK(11);
+      // the lower nv x nv block of f_u resp. of its slab; entry idx = i + j nv
       {
         int i = lane % N, j = lane / N, idx = lane;
 #pragma unroll
@@ -537,11 +589,13 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
             const int off = i + j * n;
             if (pp == 0) { fu[off] = 0.0; fu[N + off] = s_Mi[idx] * dt; }
             else {
-              slab_ux[off] = 0.0;
+              if (!wide) slab_ux[off] = 0.0;
               if (pp <= N) {
                 double fbv;
                 if constexpr (PRE) fbv = fb[u]; else fbv = fu[N + off];
-                slab_ux[N + off] = (s_Mi[idx] * dt - fbv) / eps;             // problem.hpp:138-140
+                double fuv = s_Mi[idx] * dt;
+                value_fence(fuv);
+                slab_ux[N + off] = (fuv - fbv) / eps;                       // problem.hpp:138-140
               } else slab_ux[N + off] = 0.0;              // a v direction: the same M^-1, fu_ == fu
             }
           }
@@ -554,8 +608,8 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
   }
 #ifdef DEV_ANA_CLOCKS
   if (lane == 0 && ap.stage == 1 && (e == 5 * P + 3 || e == 17 * P + 50 || e == 100 * P + 1))
-    printf("ana_eval pp=%d: setup %llu aba/load %llu levels %llu body1 %llu composite %llu body2 %llu zero %llu assemble %llu store/minv %llu out %llu total %llu\n", pp,
-           clk[1] - clk[0], 0ull, clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3], clk[5] - clk[4], clk[6] - clk[5], clk[7] - clk[6], clk[8] - clk[7], clk[9] - clk[8], (FUSED ? clk[9] : clk[8]) - clk[0]);
+    printf("ana_eval pp=%d: setup %llu aba/load %llu levels %llu body1 %llu composite %llu body2 %llu zero %llu assemble %llu store/minv %llu out %llu (mfma %llu zero %llu fu %llu) total %llu\n", pp,
+           clk[1] - clk[0], 0ull, clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3], clk[5] - clk[4], clk[6] - clk[5], clk[7] - clk[6], clk[8] - clk[7], clk[9] - clk[8], clk[10] - clk[8], clk[11] - clk[10], clk[9] - clk[11], (FUSED ? clk[9] : clk[8]) - clk[0]);
 #endif
 }
 
@@ -669,6 +723,7 @@ __global__ __launch_bounds__(AW) void ana_out_kernel(AnaParams ap) {
         // first_order_deriv, problem.hpp:499-501: fx_bot = dt * d qdd/dx (+ I on the v block)
         double val = (-acc[q]) * dt;
         if (j >= N && j - N == r) val = val + 1.0;
+        value_fence(val);
         const int64_t off = (N + r) + (int64_t)j * n;
         if (pp == 0) fx[off] = val;
         else {
@@ -691,7 +746,11 @@ __global__ __launch_bounds__(AW) void ana_out_kernel(AnaParams ap) {
     const int i = k % n, j = k / n;
     const int64_t off = i + (int64_t)j * n;
     if (pp == 0) fu[off] = i < N ? 0.0 : Mi[(i - N) + (int64_t)j * N] * dt;
-    else if (pp <= N) slab_ux[off] = i < N ? 0.0 : (Mi[(i - N) + (int64_t)j * N] * dt - fu[off]) / eps;   // problem.hpp:138-140
+    else if (pp <= N) {
+      double fuv = i < N ? 0.0 : Mi[(i - N) + (int64_t)j * N] * dt;
+      value_fence(fuv);
+      slab_ux[off] = i < N ? 0.0 : (fuv - fu[off]) / eps;               // problem.hpp:138-140
+    }
     else slab_ux[off] = 0.0;                              // a v direction: the same M^-1, fu_ == fu
   }
 }
@@ -851,9 +910,10 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
   ap.write_f = do_f ? 1 : 0;
   ap.Fws = (stage == 1 && do_eq) ? ctx->ana_F : nullptr;
   if (stage == 1 && do_eq && !ctx->ana_F) return DDP_HIP_E_UNSUPPORTED;
-  if (stage == 1 && do_f) {
-    // f_uu is exactly zero (see the header of this file)
+  if (stage == 1 && do_f && !ctx->fuu_zero) {
+    // f_uu is exactly zero (see the header of this file); it stays so until someone else writes the sequence (ctx.hip clears the flag)
     HIP_TRY(hipMemsetAsync(p.fuu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_FUU].size * d.batch), ctx->stream));
+    ctx->fuu_zero = true;
   }
   if (stage == 1 && ctx->ana_A && ctx->lin_static && p.qcache) {
     // the forward dynamics of the 2 nv perturbed points: the static first-order kernels evaluate exactly these points
