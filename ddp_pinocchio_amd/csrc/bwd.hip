@@ -34,7 +34,9 @@ struct BwdParams {
   int64_t* restarts;
   const BwdJob* jobs;
   const BwdJob* jobs_half;   // K3h's job list (bwd_split.h: bwd_contract_half), or null
-  int32_t njobs_half, pad2_;
+  int32_t njobs_half;
+  int32_t half_mode;         // 1: symmetric tensors with two-entry upper halves (static mode-2 stencil); 2: this context's analytic mode-1
+                             // tensors -- no symmetry, the upper half of every f_xx / f_ux column and all of f_uu exact zeros
   int32_t has_tensors;
   int32_t b0;          // first instance of the group this launch sweeps
   int32_t c_accumulate; // K3's epilogue adds its contraction to what is already in the Q workspace (bwd_v2.h) instead of storing it
@@ -408,8 +410,12 @@ BwdParams make_params(ddp_hip_ctx* ctx) {
   p.jobs = p.sym_tensors ? ctx->jobs_sym_d : ctx->jobs_d;
   // K3h needs both structural facts: symmetry and the zero configuration rows (the static stencil's own tensors)
   const bool half = p.sym_tensors && ctx->tensor_tops_zero && ctx->tensor_tops_sparse && ctx->jobs_half_d && getenv("DDP_HIP_K3_NO_HALF") == nullptr;
-  p.jobs_half = half ? ctx->jobs_half_d : nullptr;
-  p.njobs_half = half ? ctx->njobs_half : 0;
+  // ... or the structure the analytic mode-1 pass leaves (lin_analytic.hip): q+ = q + dt v has constant jacobian rows and M^-1 does
+  // not depend on u, so the upper halves and f_uu are zeros it wrote itself
+  const bool half_m1 = !half && ctx->fuu_zero && ctx->model_h.fd_mode == 1 && ctx->jobs_half_d && getenv("DDP_HIP_K3_NO_HALF") == nullptr;
+  p.jobs_half = (half || half_m1) ? ctx->jobs_half_d : nullptr;
+  p.njobs_half = (half || half_m1) ? ctx->njobs_half : 0;
+  p.half_mode = half ? 1 : (half_m1 ? 2 : 0);
   p.has_tensors = (ctx->flags & DDP_HIP_FLAG_NO_TENSORS) ? 0 : 1;
   return p;
 }
@@ -575,7 +581,7 @@ int launch_sweep_v2(ddp_hip_ctx* ctx, const BwdParams& p0) {
   // profiled sweeps take the direct path: events recorded by a graph's event-record nodes cannot be read back with
   // hipEventElapsedTime on this ROCm (hipErrorInvalidHandle -- tried)
   if (!ctx->bwd_use_graph || (ctx->profile_mask & bwd_mask)) return enqueue_sweep_v2<NC, MC>(ctx, p0);
-  const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1) | ((uint64_t)p0.sym_tensors << 2) | ((uint64_t)(p0.jobs_half != nullptr) << 3);
+  const uint64_t key_misc = (uint64_t)p0.has_tensors | ((uint64_t)(p0.vx_trace != nullptr) << 1) | ((uint64_t)p0.sym_tensors << 2) | ((uint64_t)(p0.jobs_half != nullptr) << 3) | ((uint64_t)p0.half_mode << 4);
   auto find = [&](const void* key_x) -> ddp_hip_ctx::BwdGraph* {
     for (auto& g : ctx->bwd_graph)
       if (g.exec && g.key_x == key_x && g.key_misc == key_misc) return &g;

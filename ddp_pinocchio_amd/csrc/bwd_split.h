@@ -178,6 +178,7 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(Bwd
   const int64_t T = p.d.T;
   const int tid = threadIdx.x;
   const int kind = job.kind, c0 = job.c0, cn = job.cn;
+  const bool m1 = p.half_mode == 2;            // analytic mode-1 tensors: every column read, no upper-half entries, f_uu all zeros
   const int64_t bt = (int64_t)b * T + t;
   const double* Vx = p.ws_V + (int64_t)b * (n + n * n);
   double* C = p.c_accumulate == 2 ? p.ws_D + (int64_t)b * (n * n + m * n + m * m)
@@ -201,10 +202,10 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(Bwd
   // read at all (symmetric tensors: j >= slab)
   auto col_info = [&](int u, int jj, int& slab, int& j, bool& xcol) -> bool {
     if (kind == 10) {
-      if (u < 2) { slab = c0 + u; j = jj; xcol = true; return j >= slab; }                // f_xx(:, j, slab)
+      if (u < 2) { slab = c0 + u; j = jj; xcol = true; return m1 || j >= slab; }          // f_xx(:, j, slab)
       slab = c0 + (jj >= m ? 1 : 0); j = jj >= m ? jj - m : jj; xcol = false; return true;   // f_ux(:, j, slab)
     }
-    slab = c0 + 2 * u + (jj >= m ? 1 : 0); j = jj >= m ? jj - m : jj; xcol = false; return j >= slab;   // f_uu(:, j, slab)
+    slab = c0 + 2 * u + (jj >= m ? 1 : 0); j = jj >= m ? jj - m : jj; xcol = false; return m1 || j >= slab;   // f_uu(:, j, slab)
   };
   f64x2 buf0[HS::R], buf1[HS::R], buf2[HS::R], buf3[HS::R];
   double top0[2], top1[2], top2[2], top3[2];   // lane jj < N: the (at most) two entries of its column's upper half
@@ -216,14 +217,14 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(Bwd
       bool need = r < HS::R - 1 || f < HS::TOTAL;
       const int jj = f / HS::HP, ip = f - jj * HS::HP;
       int slab, j; bool xcol;
-      if (need) need = col_info(u, jj < n ? jj : n - 1, slab, j, xcol);
+      if (need) need = col_info(u, jj < n ? jj : n - 1, slab, j, xcol) && !(m1 && kind == 11);
       if (need) buf[r] = BWD_NT ? __builtin_nontemporal_load(&base[jj * (N / 2) + HS::HP + ip]) : base[jj * (N / 2) + HS::HP + ip];
       else buf[r] = f64x2{0.0, 0.0};
     }
     top[0] = 0.0; top[1] = 0.0;
     if (tid < n) {
       int slab, j; bool xcol;
-      if (col_info(u, tid, slab, j, xcol) && kind == 10) {          // f_uu: its directions are controls, the upper half is all zeros
+      if (col_info(u, tid, slab, j, xcol) && kind == 10 && !m1) {   // f_uu: its directions are controls, the upper half is all zeros
         const double* colp = unit_base(u) + (int64_t)tid * n;
         top[0] = colp[slab % M];                                     // the slab's direction is an x direction (f_xx and f_ux)
         if (xcol && (j % M) != (slab % M)) top[1] = colp[j % M];
@@ -244,9 +245,9 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(Bwd
     int slab, j; bool xcol;
     if (col_info(u, jj, slab, j, xcol)) {                  // (else: the mirror image, written by the job of the other column)
       if (kind == 10) {
-        if (u < 2) { dst = Cxx + j + slab * n; if (j > slab) dm = Cxx + slab + j * n; }
+        if (u < 2) { dst = Cxx + j + slab * n; if (j > slab && !m1) dm = Cxx + slab + j * n; }
         else dst = Cux + j + slab * m;
-      } else { dst = Cuu + j + slab * m; if (j > slab) dm = Cuu + slab + j * m; }
+      } else { dst = Cuu + j + slab * m; if (j > slab && !m1) dm = Cuu + slab + j * m; }
       if (p.c_accumulate == 1) { old_d = *dst; if (dm) old_m = *dm; }
     }
   }
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(BSF, BWD_WAVES_PER_SIMD) void bwd_contract_half(Bwd
       int slab, j; bool xcol;
       const bool need = col_info(u, tid, slab, j, xcol);
       double sacc = 0.0;
-      if (need && kind == 10) {
+      if (need && kind == 10 && !m1) {
         // the upper half's partials, in bwd_contract's order: row pair (2 ip, 2 ip + 1), ip ascending; all others are zeros
         const int ra = slab % M, rb = xcol ? j % M : ra;
         const int lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;

@@ -528,6 +528,8 @@ extern "C" int64_t ddp_hip_bwd_stream_bytes(const ddp_hip_ctx* ctx) {
     const int64_t cxx = n * (n + 1) / 2, cux = n * m, cuu = m * (m + 1) / 2;
     return 8 * ((cxx + cux + cuu) * (n - m) + 2 * cxx - n + cux);       // lower halves + two entries per f_xx column (one on its diagonal), one per f_ux column
   }
+  if (fast && !half && ctx->fuu_zero && ctx->model_h.fd_mode == 1 && ctx->jobs_half_d && getenv("DDP_HIP_K3_NO_HALF") == nullptr)
+    return 8 * (n * n + n * m) * (n - m);                                // analytic mode 1: the lower halves of f_xx and f_ux, nothing of f_uu
   if (sym) return 8 * (n * (n * (n + 1) / 2) + n * n * m + n * (m * (m + 1) / 2));
   return 8 * (n * n * n + n * n * m + n * m * m);
 }

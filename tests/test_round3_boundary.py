@@ -186,3 +186,45 @@ def test_k3h_bit_for_bit_at_size(gpu, monkeypatch):
         for a_, b_ in zip(half, dense):
             assert np.array_equal(a_, b_)
         assert np.all(np.isfinite(half[0])) and float(np.max(np.abs(half[2]))) > 0
+
+
+@pytest.mark.gpu
+def test_k3h_on_analytic_mode1_tensors_bit_for_bit(gpu, monkeypatch):
+    """Analytic mode 1 (lin_analytic.hip) leaves tensors with a structure of its own: the configuration rows of every f_xx / f_ux
+    column are zeros it wrote itself (q+ = q + dt v has constant jacobian rows) and f_uu is zero (M^-1 does not depend on u), but
+    f_xx is NOT symmetric (a forward difference of jacobians).  K3h then reads the lower half of every column and nothing of
+    f_uu (half_mode 2): the sweep must match the dense kernel (DDP_HIP_K3_NO_HALF=1) bit for bit, and uploaded tensors must
+    drop the assumption."""
+    capi = gpu
+    T, B = 12, 3
+    model, spec, o = make("tree38", T, batch=B, fd_mode=1, first_order_fd=0)
+    full_bytes = 8 * (o.n ** 3 + o.n * o.n * o.m + o.n * o.m * o.m)
+    with capi.Context(spec, flags=capi.FLAG_TRACE) as ctx:
+        us = np.stack([0.1 * np.random.default_rng(500 + g).normal(size=T * o.m) for g in range(B)])
+        ctx.upload("X", np.zeros((B, (T + 1) * o.nx))); ctx.upload("U", us)
+        ctx.rollout()
+        assert ctx.bwd_stream_bytes() == full_bytes                               # nothing known about the tensors yet
+        ctx.linearize()
+        assert ctx.bwd_stream_bytes() == 8 * (o.n * o.n + o.n * o.m) * (o.n - o.m)
+        fxx = ctx.download("FXX")[0].reshape(T, o.n, o.n, o.n)                    # [t][i][j][k]
+        fux = ctx.download("FUX")[0].reshape(T, o.n, o.m, o.n)
+        assert not np.any(fxx[..., :o.m]) and not np.any(fux[..., :o.m]) and not np.any(ctx.download("FUU"))
+        assert not np.array_equal(fxx, fxx.transpose(0, 2, 1, 3))
+        ctx.upload("LFX", 0.1 * np.random.default_rng(7).normal(size=(B, o.n)))
+        ctx.upload("LFXX", np.tile(np.eye(o.n).reshape(-1), (B, 1)))
+
+        def sweep():
+            rc, reg, mu, rs = ctx.backward(0.0, 1.0, 8)
+            return ctx.download("FB_JAC"), ctx.download("FB_VAL"), ctx.download("VX_TRACE"), rs, reg, mu
+        half = sweep()
+        monkeypatch.setenv("DDP_HIP_K3_NO_HALF", "1")
+        dense = sweep()
+        monkeypatch.delenv("DDP_HIP_K3_NO_HALF")
+        for a_, b_ in zip(half, dense):
+            assert np.array_equal(a_, b_)
+        assert np.all(np.isfinite(half[0])) and float(np.max(np.abs(half[2]))) > 0
+        ctx.upload("FUX", ctx.download("FUX"))                                    # tensors from outside: the full read again
+        assert ctx.bwd_stream_bytes() == full_bytes
+        again = sweep()
+        for a_, b_ in zip(half, again):
+            assert np.array_equal(a_, b_)
