@@ -328,6 +328,10 @@ def main():
         if world == 1 and not a.no_extra and S != 1:
             extra["config3_single_instance"] = single_instance_leg(capi, a, model, local_rank, T)
             if full and a.fd_mode == 2:
+                try:
+                    extra["reference_drivers_mode1"] = mode1_leg(capi, a, model, local_rank, T)
+                except Exception as exc:
+                    extra["reference_drivers_mode1"] = {"error": repr(exc)}
                 for key, name in (("constrained_frame", "tree38_frame"), ("constrained_config", "tree38_config"),
                                   ("config5_free_flyer_frame", "tree38ff_frame")):
                     try:
@@ -362,6 +366,31 @@ def single_instance_leg(capi, a, model, device, T):
     ctx.close()
     return {"workload": f"1 instance x {a.n_alpha} alphas, T={T}", "iterations_per_s": k / el, "ms_per_iteration": el / k * 1e3,
             "phases_ms": {p: v / k for p, v in it.phase_ms.items()}}
+
+
+def mode1_leg(capi, a, model, device, T):
+    """The headline workload in the derivative mode of the reference's own drivers (test/pinocchio_ddp.cpp:60,
+    dy{model, dt, false} + second_order_finite_diff mode 1): analytic f_x, f_u (computeABADerivatives restated) and their
+    forward differences as tensors -- same seeds, same inputs, full DDP."""
+    import copy
+    b = copy.copy(a)
+    b.fd_mode = 1
+    S = a.seeds_per_gpu
+    ctx = make_instances(capi, b, model, list(range(S)), device, T)
+    it = Iterator(ctx, S, a.n_alpha)
+    it.step(False)
+    ctx.synchronize()
+    k = 3
+    t0 = time.perf_counter()
+    for _ in range(k):
+        it.step(True)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    info = ctx.info()
+    ctx.close()
+    return {"workload": f"{S} seeds x {a.n_alpha} alphas, T={T}, analytic first order + fd_mode 1", "iterations_per_s": S * k / el,
+            "ms_per_step": el / k * 1e3, "phases_ms": {p: v / k for p, v in it.phase_ms.items()},
+            "paths": {"lin_path": info["lin_path"], "first_order": info["first_order"], "bwd_path": info["bwd_path"], "fwd_path": info["fwd_path"]}}
 
 
 def constrained_leg(capi, a, name, device, T, seeds=None, iters=2):
