@@ -301,7 +301,7 @@ def main():
                        "n_alpha": a.n_alpha, "parallelism": f"seeds x{world}", "paths": info},
             "roofline": {"kernel": "bwd_contract (K3: V_x-contracted f_xx, f_ux, f_uu)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(S / launches_per_sweep),
+                         "traffic": pmc_traffic(S / launches_per_sweep, a.fd_mode if full else 0),
                          "bytes_per_launch": bytes_read, "avg_launch_us": avg_s * 1e6, "launches": n_a,
                          "survey_formula_bytes_per_launch": bytes_per_launch, "survey_formula_gbs": survey_gbs,
                          "survey_formula_frac": survey_gbs / HBM_PEAK_GBS,
@@ -494,12 +494,13 @@ def constrained_leg(capi, a, name, device, T, seeds=None, iters=2):
     return out
 
 
-def pmc_traffic(S):
+def pmc_traffic(S, fd_mode):
     """HBM bytes per K3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 for gfx950's wide-read
     under-count + WRITE_SIZE, separate --pmc runs: profiles/k3_traffic.json), valid for the profiled batch only"""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
-        return float(rec["bytes_per_launch"]) if int(rec["batch"]) == int(round(S)) and not os.environ.get("DDP_HIP_K3_NO_HALF") else None
+        same = int(rec["batch"]) == int(round(S)) and int(rec.get("fd_mode", 2)) == int(fd_mode) and not os.environ.get("DDP_HIP_K3_NO_HALF")
+        return float(rec["bytes_per_launch"]) if same else None
     except Exception:
         return None
 
