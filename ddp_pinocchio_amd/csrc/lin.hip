@@ -1017,6 +1017,7 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   else if (nv <= 6 && !ctx->model_h.ff) rc = run_linearize<6>(ctx, p, stages);   // (the one-lane constraint chain of small models is vector-space only)
   else if (nv <= 38) rc = run_linearize<38>(ctx, p, stages);
   else rc = run_linearize<64>(ctx, p, stages);
+  ctx->ana_M0_fresh = false;
   if (rc != DDP_HIP_OK) return rc;
   END_SYNC(ctx);
   // mode 2 writes one value to both (i, j, k) and (i, k, j) (problem.hpp:283-292), mode 0 leaves zeros: f_xx is symmetric bit

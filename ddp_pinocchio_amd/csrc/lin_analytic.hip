@@ -85,45 +85,85 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 // of an identity block, so that nothing below depends on nv).  Right-looking Cholesky M = L L^T, row r of L replacing row r of M;
 // then lane r solves L L^T x = e_r.  Every L(i, l) another lane needs is one lane_bcast of the owner's register: the arithmetic
 // is that of the split path's ana_minv_kernel, entry for entry.  (Entries above the diagonal are never read; they hold junk.)
+// (the broadcasts of a chunk go out together, into scalar pairs of their own, then the chunk's arithmetic: a v_readlane_b32 pair
+// followed at once by its consumer costs the hazard wait states every time)
+constexpr int BC = 8;
+template <int K, int J0, int NJ, int... U>
+__device__ __forceinline__ void chol_update_chunk(double (&a)[NJ], std::integer_sequence<int, U...>) {
+  const double l[] = {lane_bcast(a[K], J0 + U)...};                              // L(j, k) from lane j
+  ((a[J0 + U] = a[J0 + U] - a[K] * l[U]), ...);                                  // rows r >= j
+  (value_fence(a[J0 + U]), ...);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int K, int J0, int CNT, int NJ>
+__device__ __forceinline__ void chol_update(double (&a)[NJ]) {
+  if constexpr (CNT > 0) {
+    constexpr int C = CNT < BC ? CNT : BC;
+    chol_update_chunk<K, J0>(a, std::make_integer_sequence<int, C>{});
+    chol_update<K, J0 + C, CNT - C>(a);
+  }
+}
+// sx -= sum_u L(I, L0 + u) x[L0 + u] (FWD: L(I, l) is lane I's a[l]) resp. L(L0 + u, I) x[L0 + u] (lane L0 + u's a[I])
+template <bool FWD, int I, int L0, int NJ, int... U>
+__device__ __forceinline__ void subst_chunk(const double (&a)[NJ], const double (&x)[NJ], double& sx, std::integer_sequence<int, U...>) {
+  const double l[] = {(FWD ? lane_bcast(a[L0 + U], I) : lane_bcast(a[I], L0 + U))...};
+  ((sx -= l[U] * x[L0 + U]), ...);
+  value_fence(sx);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <bool FWD, int I, int L0, int CNT, int NJ>
+__device__ __forceinline__ void subst_range(const double (&a)[NJ], const double (&x)[NJ], double& sx) {
+  if constexpr (CNT > 0) {
+    constexpr int C = CNT < BC ? CNT : BC;
+    subst_chunk<FWD, I, L0>(a, x, sx, std::make_integer_sequence<int, C>{});
+    subst_range<FWD, I, L0 + C, CNT - C>(a, x, sx);
+  }
+}
+template <int K, int NJ>
+__device__ __forceinline__ void chol_steps(double (&a)[NJ], double& my_dinv, int r) {
+  if constexpr (K < NJ) {
+    const double dk_own = sqrt(a[K]), di_own = 1.0 / dk_own;
+    const double dk = lane_bcast(dk_own, K), dinv_k = lane_bcast(di_own, K);
+    my_dinv = (r == K) ? di_own : my_dinv;
+    a[K] = (r == K) ? dk : a[K] * dinv_k;
+    chol_update<K, K + 1, NJ - K - 1>(a);
+    chol_steps<K + 1>(a, my_dinv, r);
+  }
+}
+template <int I, int NJ>
+__device__ __forceinline__ void fwd_rows(const double (&a)[NJ], double (&x)[NJ], double my_dinv) {
+  if constexpr (I < NJ) {
+    double sx = x[I];
+    subst_range<true, I, 0, I>(a, x, sx);
+    x[I] = sx * lane_bcast(my_dinv, I);
+    value_fence(x[I]);
+    fwd_rows<I + 1>(a, x, my_dinv);
+  }
+}
+template <int I, int NJ>
+__device__ __forceinline__ void bwd_rows(const double (&a)[NJ], double (&x)[NJ], double my_dinv) {
+  if constexpr (I >= 0) {
+    double sx = x[I];
+    subst_range<false, I, I + 1, NJ - I - 1>(a, x, sx);
+    x[I] = sx * lane_bcast(my_dinv, I);
+    value_fence(x[I]);
+    bwd_rows<I - 1>(a, x, my_dinv);
+  }
+}
 template <int NJ>
 __device__ __forceinline__ void wave_spd_inverse(double (&a)[NJ], double (&x)[NJ], int r) {
   double my_dinv = 0.0;                                   // 1 / L(r, r)
-#pragma unroll
-  for (int k = 0; k < NJ; ++k) {
-    const double dk_own = sqrt(a[k]), di_own = 1.0 / dk_own;
-    const double dk = lane_bcast(dk_own, k), dinv_k = lane_bcast(di_own, k);
-    my_dinv = (r == k) ? di_own : my_dinv;
-    a[k] = (r == k) ? dk : a[k] * dinv_k;
-#pragma unroll
-    for (int j = k + 1; j < NJ; ++j) { a[j] = a[j] - a[k] * lane_bcast(a[k], j); value_fence(a[j]); }   // rows r >= j; L(j, k) from lane j
-    __builtin_amdgcn_sched_barrier(0);                    // (bounds the scalars the scheduler keeps in flight)
-  }
+  chol_steps<0>(a, my_dinv, r);
   // (the substitutions broadcast the same L(i, l) the factorisation did; the fences keep the compiler from parking all nv^2 / 2
   // of them in spilled scalars to save the second and third v_readlane)
 #pragma unroll
   for (int i = 0; i < NJ; ++i) value_fence(a[i]);
 #pragma unroll
   for (int i = 0; i < NJ; ++i) x[i] = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-  for (int i = 0; i < NJ; ++i) {
-    double sx = x[i];
-#pragma unroll
-    for (int l = 0; l < i; ++l) sx -= lane_bcast(a[l], i) * x[l];                 // L(i, l) from lane i
-    x[i] = sx * lane_bcast(my_dinv, i);
-    value_fence(x[i]);                                    // (keeps the row's arithmetic from being sunk below the next row's broadcasts)
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  fwd_rows<0>(a, x, my_dinv);
 #pragma unroll
   for (int i = 0; i < NJ; ++i) value_fence(a[i]);
-#pragma unroll
-  for (int i = NJ - 1; i >= 0; --i) {
-    double sx = x[i];
-#pragma unroll
-    for (int l = i + 1; l < NJ; ++l) sx -= lane_bcast(a[i], l) * x[l];             // L(l, i) from lane l
-    x[i] = sx * lane_bcast(my_dinv, i);
-    value_fence(x[i]);                                    // (keeps the row's arithmetic from being sunk below the next row's broadcasts)
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  bwd_rows<NJ - 1>(a, x, my_dinv);
 }
 
 #ifdef DEV_ANA_CLOCKS   // development: cycle stamps of one wave per launch
@@ -385,9 +425,11 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     for (int k = 0; k < NJ; ++k) arow[k] = 0.0;
   }
   CLK(6);
+  uint64_t path_mask = 0;                                 // bit i: joint i is on the lane's path (itself included)
   if (live) {
     const int j = lane;
     for (int i = j; i >= 0; i = s_par[i]) {               // i in path(j): column j of row i, and (i != j) column i of row j
+      path_mask |= 1ull << i;
       const double* wi = s_W + 30 * i;
       double Jr[6];
 #pragma unroll
@@ -397,12 +439,7 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
       for (int k = 0; k < 6; ++k) { sq += Jr[k] * Pr[24 + k]; sv += Jr[k] * Pr[30 + k]; sm += Jr[k] * Pr[k]; }
       s_T[i * W2 + j] = sq;
       s_T[i * W2 + N + j] = sv;
-      if constexpr (FUSED) {
-        if (want_M) {                                     // (a register array cannot be indexed by the run-time joint number)
-#pragma unroll
-          for (int k = 0; k < NJ; ++k) arow[k] = (k == i) ? sm : arow[k];
-        }
-      } else {
+      if constexpr (!FUSED) {
         if (want_M) { Mo[i + (int64_t)j * N] = sm; Mo[j + (int64_t)i * N] = sm; }
       }
       if (i != j) {                                       // a proper ancestor of j: its u | g
@@ -411,6 +448,20 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
         for (int k = 0; k < 6; ++k) { const double pa = wi[18 + k]; s1 += Pr[6 + k] * pa; s2 += Pr[k] * wi[24 + k]; s3 += Pr[6 + k] * Jr[k]; s4 += Pr[k] * pa; }
         s_T[j * W2 + i] = -s1 + s2;
         s_T[j * W2 + N + i] = s3 - 2.0 * s4;
+      }
+    }
+  }
+  if constexpr (FUSED) {
+    // the lane's row of M, M(j, k) = J_k . y_j for k on the path of j: a register array cannot be indexed by the run-time joint
+    // number the walk above meets, so the product is formed for EVERY k (J_k: one broadcast read) and kept where the path says so
+    if (want_M && live) {
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) {                      // (k >= nv: no bit in the mask)
+        const double* Jk = s_W + 30 * k + 12;
+        double sm = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sm += Jk[c] * Pr[c];
+        arow[k] = ((path_mask >> k) & 1) ? sm : 0.0;
       }
     }
   }
@@ -940,12 +991,13 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
     if (stage == 0) {
       ap.bt0 = 0; ap.nbt = (int32_t)BT;
       hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)BT), dim3(AW), lds, ctx->stream, ap);
+      ctx->ana_M0_fresh = ctx->ana_M0 != nullptr;         // (lin.hip drops the mark when the linearisation call returns)
       if (do_eq) hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)BT), dim3(AW), eq_lds_bytes<NJ>(d), ctx->stream, ap);
       HIP_TRY(hipGetLastError());
       return DDP_HIP_OK;
     }
     if (!ctx->ana_M0) return DDP_HIP_E_UNSUPPORTED;
-    {                                                     // M^-1 at the trajectory points, for the v directions
+    if (!ctx->ana_M0_fresh) {                             // M^-1 at the trajectory points, for the v directions (else: stage 0 of this very linearisation left it)
       AnaParams a0 = ap;
       a0.stage = 0; a0.m0_only = 1; a0.bt0 = 0; a0.nbt = (int32_t)BT; a0.Fws = nullptr; a0.accel = nullptr;
       hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)BT), dim3(AW), lds, ctx->stream, a0);
