@@ -219,7 +219,9 @@ int ddp_hip_solve(ddp_hip_ctx* ctx, const ddp_hip_solver_params* params, ddp_hip
 typedef struct ddp_hip_info {
   int32_t device;
   int32_t lin_path;       /* 0 closed form (pendulum), 1 run-time-tree kernels (any topology), 2 static TopoTalos38, 3 static TopoChain6,
-                           * >= 4 a generated static topology (tools/gen_topology.py -> csrc/topo_extra.h; shipped: 4 Arm7, 5 Biped12) */
+                           * >= 4 a generated static topology (tools/gen_topology.py -> csrc/topo_extra.h; shipped: 4 Arm7, 5 Biped12).
+                           * With first_order == 2 and fd_mode 1 a static topology means: the forward dynamics of the perturbed points come
+                           * from the static first-order kernels (one ABA per (instance, t) instead of 2 nv + 1) */
   int32_t first_order;    /* 0 analytic (pendulum_model.hpp:116-130), 1 forward FD (north star), 2 analytic ABA derivatives */
   int32_t bwd_path;       /* 0 run-time-shaped bwd_assemble / bwd_gains, 1 split K3 bwd_contract / K4 bwd_riccati */
   int32_t fwd_path;       /* 0 one lane per rollout, 1 latency path (two workgroups per instance; constrained problems: + parallel cost kernel) */

@@ -108,3 +108,58 @@ def test_generated_topology_takes_the_static_kernels_and_matches_the_oracle(gpu,
             assert float(np.max(np.abs(got[key][b] - ref))) <= tol, (key, b)
             # ... and so do the run-time-tree kernels (the A/B partner of the static path), i.e. the two agree within FD noise
             assert float(np.max(np.abs(got_g[key][b] - ref))) <= tol, (key, b, "generic")
+
+
+TREE44 = [-1, 0, 1, 2, 3, 4] + [5, 6, 7, 8, 9, 10] + [5, 12, 13, 14, 15, 16] + [5, 18] + [19, 20, 21, 22, 23, 24, 25] + \
+         [19, 27, 28, 29, 30, 31, 32] + [19, 34] + [26, 36, 37] + [33, 39, 40] + [35, 42]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parents,lin_path", [(ARM7, 4), (BIPED12, 5), (TREE44, 1)])
+def test_analytic_mode1_on_other_tree_sizes(gpu, parents, lin_path, monkeypatch):
+    """The analytic evaluation kernel (lin_analytic.hip) is instantiated for <= 38 and <= 64 joints and pads M to that size by an
+    identity block before its in-wave inverse: a 7- and a 12-joint tree (padding; static topology, so the accelerations of the
+    perturbed points come from the static first-order kernels) and a 44-joint tree (the 64 instantiation, separate T region in
+    LDS, own forward dynamics at every point) against the oracle, and the fused kernel against the three-kernel form."""
+    capi = gpu
+    from oracle.binding import Oracle
+    from test_dynamics_parity import DERIV_SEQS, TENSOR_SEQS
+    nv = len(parents)
+    assert len(TREE44) == 44 and all(p < i for i, p in enumerate(parents))
+    model = seeded_tree(parents, seed=100 + nv)
+    T = 3
+    kw = dict(dt=0.01, c=1.0, fd_mode=1, first_order_fd=0, eq_kind=capi.EQ_NONE, ne=np.zeros(T, dtype=np.int64))
+    spec = capi.ProblemSpec(model, T, batch=2, **kw)
+    o = Oracle(model, T, **kw)
+    rng = np.random.default_rng(5)
+    trajs = []
+    for b in range(2):
+        us = 0.5 * rng.normal(size=T * nv)
+        x0 = np.concatenate([0.3 * rng.normal(size=nv), 0.2 * rng.normal(size=nv)])
+        trajs.append((us, o.rollout(x0, us)))
+
+    def run():
+        with capi.Context(spec) as ctx:
+            info = ctx.info()
+            for b, (us, xs) in enumerate(trajs):
+                ctx.upload("X", xs, b, 1); ctx.upload("U", us, b, 1)
+            ctx.linearize()
+            return info, {k: ctx.download(s) for k, s in {**DERIV_SEQS, **TENSOR_SEQS}.items() if ctx.seq_size(s)}
+    info, got = run()
+    assert info["first_order"] == 2 and info["lin_path"] == lin_path
+    monkeypatch.setenv("DDP_HIP_ANA_SPLIT", "1")
+    _, split = run()
+    monkeypatch.delenv("DDP_HIP_ANA_SPLIT")
+    for key in got:
+        assert np.array_equal(got[key], split[key]), key          # same arithmetic, entry for entry
+    EPS, E1 = 2.220446049250313e-16, 1.4901161193847656e-08
+    for b, (us, xs) in enumerate(trajs):
+        d = o.compute_derivatives(xs, us)
+        jscale = max(1.0, float(np.max(np.abs(d["fx"]))), float(np.max(np.abs(d["fu"]))))
+        cond = max(float(np.linalg.cond(o.crba(xs[t * 2 * nv:t * 2 * nv + nv]))) for t in range(T))
+        for key in ("f_val", "fx", "fu", "fxx", "fux", "fuu"):
+            ref = d[key][:got[key][b].size]
+            err, scale = float(np.max(np.abs(got[key][b] - ref))), max(1.0, float(np.max(np.abs(ref))))
+            assert np.all(np.isfinite(got[key][b])), key
+            tol = 1e-12 * scale if key == "f_val" else (1e-10 * scale if key in ("fx", "fu") else 8 * EPS * cond * jscale / E1)
+            assert err <= tol, (key, b, err, tol)
