@@ -44,8 +44,8 @@ struct AnaParams {
   int32_t pad_;
   double* M0;       // fused path: [B T][nv][nv] M^-1 at the trajectory points (stage 0 writes it, the v directions of stage 1 read it)
   int32_t m0_only;  // fused path, stage 0: form M0 alone (the pre-pass of a stage-1 launch)
-  int32_t pad2_;
-  const double* accel;   // stage 1: [pair][2nv][nv] accelerations of the perturbed points, formed by the static first-order kernels
+  int32_t eq_no_aba;   // ana_eq_kernel: no evaluation of this launch runs forward dynamics (stage 1 with `accel`): no ABA state in LDS
+  const double* accel;   // stage 1: [pair][3 nv: q, v, u directions][nv] accelerations of the perturbed points, formed by the static first-order kernels
                          // (lin_static.hip, level 6) -- or null: every evaluation runs its own forward dynamics
 };
 
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
   }
   wave_sync();
   if (ap.accel != nullptr && pp >= 1) {
-    const double* __restrict__ ag = ap.accel + ((int64_t)bt * W2 + (pp - 1)) * N;
+    const double* __restrict__ ag = ap.accel + ((int64_t)bt * (3 * N) + (pp - 1)) * N;
     if (live) s_a[lane] = ag[lane];
   } else {
     rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_R1, 0, lane, true);   // ends with a barrier
@@ -840,8 +840,8 @@ __global__ __launch_bounds__(AW) void ana_eq_kernel(AnaParams ap) {
   const double eps = sqrt(DBL_EPSILON);
 
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* s_st = lds;                                   // ABA state
-  double* s_q = s_st + rbd::ABA_LDS_SLOTS * NJ;
+  double* s_st = lds;                                   // ABA state (absent when the launch runs no forward dynamics: AnaParams::eq_no_aba)
+  double* s_q = s_st + (ap.eq_no_aba ? 0 : rbd::ABA_LDS_SLOTS * NJ);
   double* s_v = s_q + NJ;
   double* s_tau = s_v + NJ;
   double* s_a = s_tau + NJ;
@@ -859,12 +859,26 @@ __global__ __launch_bounds__(AW) void ana_eq_kernel(AnaParams ap) {
     }
   }
   __syncthreads();
-  for (int k = 0; k < K; ++k) {                           // dynamics_t::eval_to, problem.hpp:441-461
-    rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_st, 0, lane, true);   // ends with a barrier
+  // the look-ahead states x_1 .. x_K (dynamics_t::eval_to, problem.hpp:441-461).  Both base constraints read q alone, so the last
+  // step needs q_K = q_{K-1} + dt v_{K-1} and no forward dynamics; the identity jacobian of the config constraint does not depend
+  // on x_K at all (a perturbed direction then needs no look-ahead state); and the acceleration at the perturbed point itself is
+  // the one the static first-order kernels formed for the dynamics' own pass (AnaParams::accel)
+  const bool need_state = dir == 0 || m.eq_kind != DDP_HIP_EQ_CONFIG;
+  for (int k = 0; k < K && need_state; ++k) {
+    const bool last = k == K - 1;
+    if (!last) {
+      if (k == 0 && dir >= 1 && ap.eq_no_aba) {
+        const double* __restrict__ ag = ap.accel + ((int64_t)bt * (3 * N) + (dir - 1)) * N;
+        for (int i = lane; i < N; i += AW) s_a[i] = ag[i];
+        __syncthreads();
+      } else {
+        rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_st, 0, lane, true);   // ends with a barrier
+      }
+    }
     for (int i = lane; i < N; i += AW) {
       const double vo = dt * s_v[i];
       s_q[i] = s_q[i] + vo;
-      s_v[i] = s_v[i] + s_a[i] * dt;
+      if (!last) s_v[i] = s_v[i] + s_a[i] * dt;
     }
     __syncthreads();
   }
@@ -907,41 +921,63 @@ __global__ __launch_bounds__(AW) void ana_eq_kernel(AnaParams ap) {
     }
     return;
   }
-  const double* ox = p.eq_x + Eb * n;
-  const double* ou = p.eq_u + Eb * N;
+  const double* __restrict__ ox = p.eq_x + Eb * n;
+  const double* __restrict__ ou = p.eq_u + Eb * N;
+  // entry idx = i + j e of an e-row block: (i, j) advance by (64 mod e, 64 div e) per pass, no division per entry
+  const int si = AW % e, sj = AW / e;
+  // config constraint: C_q = [I_e | 0], so row i of a product has ONE non-zero term (r = i); every other term of the reference's
+  // sum is 0 * finite, which leaves the running sum as it is
+  const bool ident = m.eq_kind == DDP_HIP_EQ_CONFIG;
   if (dir <= 2 * N) {
     const int idx3 = dir - 1;                             // the right index of the slab
-    const double* Fv = ap.Fws + (sbt * (2 * N) + idx3) * (int64_t)N * n;                       // v rows of f_x at the perturbed point
-    const double* Mi = ap.Mws + (sbt * (N + 1) + (dir <= N ? dir : 0)) * (int64_t)N * N;       // M^-1 of its configuration
-    double* sxx = p.eq_xx + Eb * n * n + (int64_t)idx3 * e * n;
-    double* sux = p.eq_ux + Eb * N * n + (int64_t)idx3 * e * N;
-    for (int idx = lane; idx < e * n; idx += AW) {
-      const int i = idx % e, j = idx / e;
-      // the q rows of f_x are the constants [I | dt I] (problem.hpp:487-490): one non-zero term, the others exact zeros
-      double sacc = j < N ? C1(i, j) * 1.0 : C1(i, j - N) * (1.0 * dt);
-      for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * Fv[r + (int64_t)j * N];
-      sxx[idx] = (sacc - ox[idx]) / eps;                  // problem.hpp:128-134
+    const double* __restrict__ Fv = ap.Fws + (sbt * (2 * N) + idx3) * (int64_t)N * n;                   // v rows of f_x at the perturbed point
+    const double* __restrict__ Mi = ap.Mws + (sbt * (N + 1) + (dir <= N ? dir : 0)) * (int64_t)N * N;  // M^-1 of its configuration
+    double* __restrict__ sxx = p.eq_xx + Eb * n * n + (int64_t)idx3 * e * n;
+    double* __restrict__ sux = p.eq_ux + Eb * N * n + (int64_t)idx3 * e * N;
+    {
+      int i = lane % e, j = lane / e;
+#pragma unroll 4
+      for (int idx = lane; idx < e * n; idx += AW) {
+        // the q rows of f_x are the constants [I | dt I] (problem.hpp:487-490): one non-zero term, the others exact zeros
+        double sacc = j < N ? C1(i, j) * 1.0 : C1(i, j - N) * (1.0 * dt);
+        if (ident) sacc += C1(i, N + i) * Fv[i + j * N];
+        else for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * Fv[r + j * N];
+        sxx[idx] = (sacc - ox[idx]) / eps;                // problem.hpp:128-134
+        i += si; j += sj;
+        if (i >= e) { i -= e; ++j; }
+      }
     }
-    for (int idx = lane; idx < e * N; idx += AW) {
-      const int i = idx % e, j = idx / e;
-      double sacc = 0.0;                                  // the q rows of f_u are zero (problem.hpp:493)
-      for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * (Mi[r + (int64_t)j * N] * dt);
-      sux[idx] = (sacc - ou[idx]) / eps;                  // problem.hpp:135-137
+    {
+      int i = lane % e, j = lane / e;
+#pragma unroll 4
+      for (int idx = lane; idx < e * N; idx += AW) {
+        double sacc = 0.0;                                // the q rows of f_u are zero (problem.hpp:493)
+        if (ident) sacc += C1(i, N + i) * (Mi[i + j * N] * dt);
+        else for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * (Mi[r + j * N] * dt);
+        sux[idx] = (sacc - ou[idx]) / eps;                // problem.hpp:135-137
+        i += si; j += sj;
+        if (i >= e) { i -= e; ++j; }
+      }
     }
   } else {
     const int idx3 = dir - 1 - 2 * N;
-    double* suu = p.eq_uu + Eb * N * N + (int64_t)idx3 * e * N;
+    double* __restrict__ suu = p.eq_uu + Eb * N * N + (int64_t)idx3 * e * N;
+    const double* __restrict__ fur = fu;
+    int i = lane % e, j = lane / e;
+#pragma unroll 4
     for (int idx = lane; idx < e * N; idx += AW) {
-      const int i = idx % e, j = idx / e;
       double sacc = 0.0;
-      for (int l = 0; l < n; ++l) sacc += C1(i, l) * fu[l + (int64_t)j * n];   // f_u(x, u + eps e) == f_u(x, u), bit for bit
+      if (ident) { sacc += C1(i, i) * fur[i + j * n]; sacc += C1(i, N + i) * fur[N + i + j * n]; }
+      else for (int l = 0; l < n; ++l) sacc += C1(i, l) * fur[l + j * n];   // f_u(x, u + eps e) == f_u(x, u), bit for bit
       suu[idx] = (sacc - ou[idx]) / eps;                  // problem.hpp:141-145
+      i += si; j += sj;
+      if (i >= e) { i -= e; ++j; }
     }
   }
 }
 
 template <int NJ>
-size_t eq_lds_bytes(const Dims& d) { return sizeof(double) * (size_t)(rbd::ABA_LDS_SLOTS * NJ + 4 * NJ + d.emax * NJ); }
+size_t eq_lds_bytes(const Dims& d, bool no_aba = false) { return sizeof(double) * (size_t)((no_aba ? 0 : rbd::ABA_LDS_SLOTS * NJ) + 4 * NJ + d.emax * NJ); }
 
 // flags: ANA_F the dynamics' own outputs (stage 0: f_x, f_u; stage 1: f_xx, f_ux, f_uu), ANA_EQ the constraint chain's
 // (stage 0: eq_val, eq_x, eq_u from the resident f_x, f_u; stage 1: eq_xx, eq_ux, eq_uu)
@@ -971,9 +1007,10 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
     // (x + sqrt(eps_mach) e_k) chain-wise from the base point's cache, ~25x cheaper than one cooperative ABA per point
     LinParams pa = p;
     pa.accel_out = ctx->ana_A;
-    const int rc_ = lin_static_launch(ctx, pa, 6);
+    const int rc_ = lin_static_launch(ctx, pa, do_eq ? 7 : 6);   // the constraint chain also differences along the u directions
     if (rc_ != DDP_HIP_OK) return rc_;
     ap.accel = ctx->ana_A;
+    ap.eq_no_aba = (do_eq && ctx->model_h.eq_advance <= 2) ? 1 : 0;   // K <= 2: the one acceleration a direction needs is in ana_A
   }
   const int P = stage == 0 ? 1 : 2 * N + 1, C = stage == 0 ? 1 : N + 1;
   if (stage == 0 && !do_f) {
@@ -1008,7 +1045,7 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
       ap.bt0 = bt0;
       ap.nbt = (int32_t)nb;
       hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)(nb * 2 * N)), dim3(AW), lds, ctx->stream, ap);
-      if (do_eq) hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)(nb * 3 * N)), dim3(AW), eq_lds_bytes<NJ>(d), ctx->stream, ap);
+      if (do_eq) hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)(nb * 3 * N)), dim3(AW), eq_lds_bytes<NJ>(d, ap.eq_no_aba != 0), ctx->stream, ap);
     }
     HIP_TRY(hipGetLastError());
     return DDP_HIP_OK;
@@ -1045,7 +1082,7 @@ int lin_analytic_setup(ddp_hip_ctx* ctx) {
   if (ctx->ana_split || (m1 && d.Etot > 0)) HIP_TRY(hipMalloc(&ctx->ana_M, sizeof(double) * (size_t)(ctx->ana_nbt * (N + 1) * N * N)));
   if (!ctx->ana_split && m1) HIP_TRY(hipMalloc(&ctx->ana_M0, sizeof(double) * (size_t)(BT * N * N)));
   if (ctx->lin_static && ctx->lin_ws && ctx->model_h.fd_mode == 1 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS))
-    HIP_TRY(hipMalloc(&ctx->ana_A, sizeof(double) * (size_t)(BT * 2 * N * N)));
+    HIP_TRY(hipMalloc(&ctx->ana_A, sizeof(double) * (size_t)(BT * 3 * N * N)));
   if (d.Etot > 0) {
     // the constraint chain on analytic jacobians (ana_eq_kernel): K <= 2 look-ahead steps, see the kernel's header
     if (ctx->model_h.eq_advance < 1 || ctx->model_h.eq_advance > 2) return DDP_HIP_E_UNSUPPORTED;

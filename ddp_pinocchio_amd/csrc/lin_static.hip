@@ -1287,9 +1287,9 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
   typedef __attribute__((address_space(4))) const LinParams* kernarg_t;
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   __syncthreads();
-  if constexpr (!DIAG && LEVEL != 3) {
-    if (double* ao = kp->accel_out) {           // accelerations of the nv perturbed points of this level, for the analytic mode-1 pass
-      ao += (bt * n + (LEVEL == 2 ? nv : 0)) * nv;
+  if constexpr (!DIAG) {
+    if (double* ao = kp->accel_out) {           // accelerations of the nv perturbed points of this level ([pair][3 nv directions: q, v, u][nv]), for the analytic mode-1 pass
+      ao += (bt * (3 * nv) + (LEVEL - 1) * nv) * nv;
       for (int e = lane; e < nv * nv; e += LBS) { const int c = e / nv; ao[e] = s_q[c * (nv + 1) + (e - c * nv)]; }
       return;
     }
@@ -1579,7 +1579,7 @@ static int lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level) 
   } else if (level == 5) {                        // q- and v-caches
     hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
     if (p.nvcfg > 1) hipLaunchKernelGGL((lin_static_vcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
-  } else if (level == 6) {                        // accelerations at x + sqrt(eps_mach) e_k (p.accel_out), after the base caches
+  } else if (level == 6 || level == 7) {          // accelerations at x + sqrt(eps_mach) e_k (level 7: and u + sqrt(eps_mach) e_k) -> p.accel_out, after the base caches
     if (!p.accel_out) return DDP_HIP_E_ARG;
     hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
     const int64_t per = ctx->lin_qws_bt * GU;
@@ -1588,6 +1588,7 @@ static int lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level) 
       hipLaunchKernelGGL((lin_static_first_kernel<T, 1, false>), dim3((unsigned)nb), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, bt0);
     }
     hipLaunchKernelGGL((lin_static_first_kernel<T, 2, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
+    if (level == 7) hipLaunchKernelGGL((lin_static_first_kernel<T, 3, false>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.qcache, p.x, p.u, ctx->lin_qws, (int64_t)0);
   } else if (level == 0) {                        // first order
     const int64_t per = ctx->lin_qws_bt * GU;     // one wave per (instance, t) uses one of the GU workspace slots of a slice entry
     for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
