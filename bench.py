@@ -284,6 +284,8 @@ def main():
         # tensor bytes the stencil writes: all of them, less the mirror images the symmetric sweep never reads (formed on demand)
         # (what the sweep never reads -- mirror images, zero configuration rows -- is not written either: the same byte count)
         lin2_bytes = float(stream) * S * T if full else 0.0
+        if full and a.fd_mode == 1:                               # the analytic mode-1 pass writes every f_xx / f_ux slab whole (zero rows included)
+            lin2_bytes = 8.0 * (n_ ** 3 + n_ * n_ * m_) * S * T
         out = {
             "metric": "DDP iterations/sec (fwd+bwd sweep), Talos nq=38 T=200",
             "value": total * a.steps / elapsed,
@@ -498,7 +500,7 @@ def pmc_traffic(S, fd_mode):
     """HBM bytes per K3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 for gfx950's wide-read
     under-count + WRITE_SIZE, separate --pmc runs: profiles/k3_traffic.json), valid for the profiled batch only"""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic_mode1.json" if int(fd_mode) == 1 else "k3_traffic.json")))
         same = int(rec["batch"]) == int(round(S)) and int(rec.get("fd_mode", 2)) == int(fd_mode) and not os.environ.get("DDP_HIP_K3_NO_HALF")
         return float(rec["bytes_per_launch"]) if same else None
     except Exception:
