@@ -485,6 +485,19 @@ def constrained_leg(capi, a, name, device, T, seeds=None, iters=2):
             out["full_ddp"] = {"sweep": "Q_uu not positive definite within 8 restarts at this horizon in double (as on the CPU restatement of "
                                         "the reference's algorithm: DESIGN.md 4d); tensors generated and timed, the iterations below run tensor-free",
                                "linearize_ms": (time.perf_counter() - t0) * 1e3, "paths": ctx.info()}
+    if "ff" not in name:
+        # the same problem linearised in the reference drivers' derivative mode (analytic jacobians + their forward differences,
+        # constraint tensors included; the reference asserts nq == nv in this mode, so not for the free-flyer shape)
+        try:
+            _, spec1, _ = make(name, T, batch=S, fd_mode=1, first_order_fd=0)
+            with capi.Context(spec1, device=device) as ctx:
+                load(ctx)
+                ctx.linearize(); ctx.synchronize()
+                t0 = time.perf_counter()
+                ctx.linearize(); ctx.synchronize()
+                out["reference_drivers_mode1"] = {"linearize_ms": (time.perf_counter() - t0) * 1e3, "paths": ctx.info()}
+        except Exception as exc:
+            out["reference_drivers_mode1"] = {"error": repr(exc)}
     if "iterations_per_s" not in out["full_ddp"]:
         _, spec0, _ = make(name, T, batch=S, fd_mode=0)
         with capi.Context(spec0, device=device, flags=capi.FLAG_NO_TENSORS) as ctx:

@@ -44,6 +44,8 @@ struct AnaParams {
   int32_t pad_;
   double* M0;       // fused path: [B T][nv][nv] M^-1 at the trajectory points (stage 0 writes it, the v directions of stage 1 read it)
   int32_t m0_only;  // fused path, stage 0: form M0 alone (the pre-pass of a stage-1 launch)
+  int32_t eq_inline;   // fused path, stage 1, config constraint: eq_xx / eq_ux slabs are written by the evaluation's own wave (no Fws / Mws, no ana_eq launch)
+  int32_t pad3_;
   int32_t eq_no_aba;   // ana_eq_kernel: no evaluation of this launch runs forward dynamics (stage 1 with `accel`): no ABA state in LDS
   const double* accel;   // stage 1: [pair][3 nv: q, v, u directions][nv] accelerations of the perturbed points, formed by the static first-order kernels
                          // (lin_static.hip, level 6) -- or null: every evaluation runs its own forward dynamics
@@ -534,9 +536,18 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     // D'(j, r) = sum_l T(l, j) Minv(l, r): A(row = j, k = l) = T(l, j), B(k = l, col = r) = Minv(l, r); tiles 16 x 16, k by 4.
     // Result register q of a lane: D'(row = 16 jt + l4 + 4 q, col = 16 rt + l15)
     const int JT = (W2 + 15) / 16;
-    // the destination of a result is wave-uniform (kind 0: the trajectory point's f_x; 1: its f_xx slab; 2: the workspace of the
-    // constraint chain alone; 3: both): one specialised copy of the loop per kind, so the loop body carries no uniform branches
+    // the destinations of a result are wave-uniform (bits: 1 the trajectory point's f_x, 2 its f_xx slab, 4 the workspace of the
+    // constraint chain, 8 the config constraint's eq_xx slab formed on the spot): one specialised copy of the loop per
+    // combination, so the loop body carries no uniform branches
     double* fws = ap.Fws ? ap.Fws + (sbt * (2 * N) + (pp - 1)) * (int64_t)N * n : nullptr;
+    // config constraint (C_q = [I_e | 0], K time shifts): eq_x' = [C_q | dt C_q] f_x' has the one-term rows of ana_eq_kernel's `ident`
+    // path, so the slab eq_xx(:, :, p-1) = (eq_x' - eq_x) / eps comes straight out of this wave's v rows of f_x'
+    const int e_t = ap.eq_inline ? (int)p.ne[t] : 0;
+    const bool eqi = e_t > 0 && pp > 0;
+    const int64_t Eb = eqi ? (int64_t)b * p.d.Etot + p.Epre[t] : 0;
+    const double dtK = m.eq_advance >= 2 ? 1.0 * dt : 0.0;             // C1(i, nv + i) of ana_eq_kernel
+    const double* __restrict__ eqx0 = p.eq_x + Eb * n;
+    double* __restrict__ eq_sxx = p.eq_xx + Eb * n * n + (int64_t)(pp - 1) * e_t * n;
     auto products = [&](auto kind_c) {
       constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
@@ -563,6 +574,16 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
           for (int rt = 0; rt < RTM; ++rt) value_fence(bv[rt][sk]);
         }
         batch_fence();
+        double oxv[(KIND & 8) ? RTM : 1][4];              // eq_x at the lane's entries: requested now, used after the products
+        if constexpr ((KIND & 8) != 0) {
+#pragma unroll
+          for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int j = 16 * jt + l4 + 4 * q, r = 16 * rt + l15;
+              oxv[rt][q] = eqx0[(j < W2 && r < e_t) ? r + j * e_t : 0];
+            }
+        }
         f64x4_ acc[RTM];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) acc[rt] = f64x4_{0.0, 0.0, 0.0, 0.0};
@@ -587,21 +608,30 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
             value_fence(val);                             // the jacobian entry as the reference rounds it, before it is differenced (no fused multiply-subtract)
             double bq;
             if constexpr (PRE) bq = base[jt][rt][q];
-            else bq = (KIND == 1 || KIND == 3) ? fx[(j < W2 && r < N) ? (N + r) + j * n : 0] : 0.0;
+            else bq = (KIND & 2) ? fx[(j < W2 && r < N) ? (N + r) + j * n : 0] : 0.0;
             if (j < W2 && r < N) {
               const int off = (N + r) + j * n;
-              if constexpr (KIND == 0) fx[off] = val;
-              if constexpr (KIND == 1 || KIND == 3) slab_xx[off] = (val - bq) / eps;     // problem.hpp:128-137
-              if constexpr (KIND == 2 || KIND == 3) fws[r + j * N] = val;
+              if constexpr ((KIND & 1) != 0) fx[off] = val;
+              if constexpr ((KIND & 2) != 0) slab_xx[off] = (val - bq) / eps;            // problem.hpp:128-137
+              if constexpr ((KIND & 4) != 0) fws[r + j * N] = val;
+              if constexpr ((KIND & 8) != 0) {
+                if (r < e_t) {
+                  const double first = j < N ? ((r == j) ? 1.0 : 0.0) * 1.0 : ((r == j - N) ? 1.0 : 0.0) * (1.0 * dt);
+                  const double eqv = fma(dtK, val, first);               // ana_eq_kernel: sacc = first; sacc += C1(i, nv + i) Fv(i, j)
+                  eq_sxx[r + j * e_t] = (eqv - oxv[rt][q]) / eps;        // problem.hpp:128-134
+                }
+              }
             }
           }
         }
       }
     };
-    if (pp == 0) products(std::integral_constant<int, 0>{});
-    else if (ap.write_f && !fws) products(std::integral_constant<int, 1>{});
-    else if (ap.write_f) products(std::integral_constant<int, 3>{});
-    else if (fws) products(std::integral_constant<int, 2>{});
+    if (pp == 0) products(std::integral_constant<int, 1>{});
+    else if (eqi && ap.write_f) products(std::integral_constant<int, 2 | 8>{});
+    else if (eqi) products(std::integral_constant<int, 8>{});
+    else if (ap.write_f && !fws) products(std::integral_constant<int, 2>{});
+    else if (ap.write_f) products(std::integral_constant<int, 2 | 4>{});
+    else if (fws) products(std::integral_constant<int, 4>{});
     CLK(10);
     if (pp == 0 || ap.write_f) {
       // the rows of q+ = q + dt v are constants (problem.hpp:487-490), so their differences are exact zeros, and f_u = [0; dt M^-1]
@@ -653,6 +683,32 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
           i += step_i; j += step_j; idx += AW;
           if (i >= N) { i -= N; ++j; }
         }
+      }
+    }
+    if (eqi) {
+      // eq_ux(:, :, p-1) = (eq_u' - eq_u) / eps with eq_u' = dt C_q f_u'(v rows) = dtK (dt M^-1(q')): entry idx = i + j nv of M^-1
+      const double* __restrict__ equ0 = p.eq_u + Eb * N;
+      double* __restrict__ eq_sux = p.eq_ux + Eb * N * n + (int64_t)(pp - 1) * e_t * N;
+      double ouv[FBN];
+      {
+        int i = lane % N, j = lane / N;
+#pragma unroll
+        for (int u = 0; u < FBN; ++u) {
+          ouv[u] = equ0[(j < N && i < e_t) ? i + j * e_t : 0];
+          i += step_i; j += step_j;
+          if (i >= N) { i -= N; ++j; }
+        }
+      }
+      int i = lane % N, j = lane / N, idx = lane;
+#pragma unroll
+      for (int u = 0; u < FBN; ++u) {
+        if (j < N && i < e_t) {
+          double fuv = s_Mi[idx] * dt;
+          value_fence(fuv);
+          eq_sux[i + j * e_t] = (fma(dtK, fuv, 0.0) - ouv[u]) / eps;   // problem.hpp:135-137
+        }
+        i += step_i; j += step_j; idx += AW;
+        if (i >= N) { i -= N; ++j; }
       }
     }
     CLK(9);
@@ -940,7 +996,7 @@ __global__ __launch_bounds__(AW) void ana_eq_kernel(AnaParams ap) {
       for (int idx = lane; idx < e * n; idx += AW) {
         // the q rows of f_x are the constants [I | dt I] (problem.hpp:487-490): one non-zero term, the others exact zeros
         double sacc = j < N ? C1(i, j) * 1.0 : C1(i, j - N) * (1.0 * dt);
-        if (ident) sacc += C1(i, N + i) * Fv[i + j * N];
+        if (ident) sacc = fma(C1(i, N + i), Fv[i + j * N], sacc);
         else for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * Fv[r + j * N];
         sxx[idx] = (sacc - ox[idx]) / eps;                // problem.hpp:128-134
         i += si; j += sj;
@@ -952,7 +1008,7 @@ __global__ __launch_bounds__(AW) void ana_eq_kernel(AnaParams ap) {
 #pragma unroll 4
       for (int idx = lane; idx < e * N; idx += AW) {
         double sacc = 0.0;                                // the q rows of f_u are zero (problem.hpp:493)
-        if (ident) sacc += C1(i, N + i) * (Mi[i + j * N] * dt);
+        if (ident) { double fuv = Mi[i + j * N] * dt; value_fence(fuv); sacc = fma(C1(i, N + i), fuv, sacc); }
         else for (int r = 0; r < N; ++r) sacc += C1(i, N + r) * (Mi[r + j * N] * dt);
         sux[idx] = (sacc - ou[idx]) / eps;                // problem.hpp:135-137
         i += si; j += sj;
@@ -1039,13 +1095,22 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
       a0.stage = 0; a0.m0_only = 1; a0.bt0 = 0; a0.nbt = (int32_t)BT; a0.Fws = nullptr; a0.accel = nullptr;
       hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)BT), dim3(AW), lds, ctx->stream, a0);
     }
-    const int64_t step = do_eq ? ctx->ana_nbt : BT;       // the constraint chain reads per-slice workspaces (Fws, Mws)
+    // config constraint: its x-direction tensors come out of the evaluation waves themselves and eq_uu is exactly zero (f_u does not
+    // depend on u and C is constant: ana_eq_kernel forms the same sum twice and differences it) -- no workspace, no slices
+    const bool eq_inline = do_eq && ctx->model_h.eq_kind == DDP_HIP_EQ_CONFIG && getenv("DDP_HIP_ANA_EQ_KERNEL") == nullptr;
+    if (eq_inline) {
+      ap.Fws = nullptr;
+      ap.eq_inline = 1;
+      HIP_TRY(hipMemsetAsync(p.eq_uu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_EQ_UU].size * d.batch), ctx->stream));
+    }
+    const bool eq_kernel = do_eq && !eq_inline;
+    const int64_t step = eq_kernel ? ctx->ana_nbt : BT;   // the constraint chain reads per-slice workspaces (Fws, Mws)
     for (int64_t bt0 = 0; bt0 < BT; bt0 += step) {
       const int64_t nb = BT - bt0 < step ? BT - bt0 : step;
       ap.bt0 = bt0;
       ap.nbt = (int32_t)nb;
       hipLaunchKernelGGL((ana_eval_kernel<NJ, true>), dim3((unsigned)(nb * 2 * N)), dim3(AW), lds, ctx->stream, ap);
-      if (do_eq) hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)(nb * 3 * N)), dim3(AW), eq_lds_bytes<NJ>(d, ap.eq_no_aba != 0), ctx->stream, ap);
+      if (eq_kernel) hipLaunchKernelGGL((ana_eq_kernel<NJ>), dim3((unsigned)(nb * 3 * N)), dim3(AW), eq_lds_bytes<NJ>(d, ap.eq_no_aba != 0), ctx->stream, ap);
     }
     HIP_TRY(hipGetLastError());
     return DDP_HIP_OK;
