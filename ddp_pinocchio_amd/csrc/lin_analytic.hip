@@ -55,13 +55,18 @@ struct AnaParams {
 //   evaluation:  R1 [78 NJ: ABA state, then per joint Ic 36 | Bc 36 | ofc 6] | W [30 NJ: oR 9 | op 3 | J 6 | ov 6 | oa 6, later u | g over
 //                ov | oa] | q, v, tau, a [4 NJ] | parent, depth (int) [NJ]
 //   assembly on: T [nv x 2nv] over the dead R1 records when it fits there (2 NJ <= 78), else behind the evaluation block;
-//                M^-1 (fused path) behind T, resp. over the dead records
+//                the image of L, then M^-1 (fused path) behind T, resp. over the dead records
+// (measured: the readlane form of the in-wave inverse 77 k cycles per wave, the LDS-image form 87 k -- the default is the former)
+#ifndef DDP_ANA_INV_LDS
+#define DDP_ANA_INV_LDS 0
+#endif
+constexpr bool INV_LDS = DDP_ANA_INV_LDS != 0;
 template <int NJ> struct AnaLds {
   static constexpr int R1 = (78 > rbd::ABA_LDS_SLOTS ? 78 : rbd::ABA_LDS_SLOTS) * NJ;
   static constexpr int W = R1, Q = W + 30 * NJ, INTS = Q + 4 * NJ, EVAL = INTS + NJ;
   static constexpr bool T_OVER = 2 * NJ <= 78;
   static constexpr int T = T_OVER ? 0 : EVAL;
-  static constexpr int X = T_OVER ? 2 * NJ * NJ : 0, X_SZ = NJ * NJ;
+  static constexpr int X = T_OVER ? 2 * NJ * NJ : 0, X_SZ = INV_LDS ? NJ * (NJ | 1) : NJ * NJ;
   static constexpr int m2(int a, int b) { return a > b ? a : b; }
   static constexpr int TOTAL = m2(EVAL, m2(T + 2 * NJ * NJ, X + X_SZ));
 };
@@ -89,83 +94,95 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 // is that of the split path's ana_minv_kernel, entry for entry.  (Entries above the diagonal are never read; they hold junk.)
 // (the broadcasts of a chunk go out together, into scalar pairs of their own, then the chunk's arithmetic: a v_readlane_b32 pair
 // followed at once by its consumer costs the hazard wait states every time)
+// LB: the L(j, k) go through an LDS image of L instead (column-major, leading dimension NJ | 1; written by the owning lane, read
+// as broadcasts, eight reads in flight per wait): an LDS read is not a VALU instruction, and a wave that is alone on its SIMD
+// issues one FP64 VALU instruction per 8 clocks -- 2 readlanes + 1 FMA per entry against 1 FMA.  (Measured slower all the same: the
+// waits on the batches cost more than the readlanes' issue slots; kept behind -DDDP_ANA_INV_LDS=1.)
 constexpr int BC = 8;
-template <int K, int J0, int NJ, int... U>
-__device__ __forceinline__ void chol_update_chunk(double (&a)[NJ], std::integer_sequence<int, U...>) {
-  const double l[] = {lane_bcast(a[K], J0 + U)...};                              // L(j, k) from lane j
+template <bool LB, int K, int J0, int NJ, int... U>
+__device__ __forceinline__ void chol_update_chunk(double (&a)[NJ], const double* sL, std::integer_sequence<int, U...>) {
+  constexpr int LD = NJ | 1;
+  const double l[] = {(LB ? sL[(J0 + U) + K * LD] : lane_bcast(a[K], J0 + U))...};   // L(j, k): lane j's a[k]
   ((a[J0 + U] = a[J0 + U] - a[K] * l[U]), ...);                                  // rows r >= j
   (value_fence(a[J0 + U]), ...);
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (LB) batch_fence(); else __builtin_amdgcn_sched_barrier(0);
 }
-template <int K, int J0, int CNT, int NJ>
-__device__ __forceinline__ void chol_update(double (&a)[NJ]) {
+template <bool LB, int K, int J0, int CNT, int NJ>
+__device__ __forceinline__ void chol_update(double (&a)[NJ], const double* sL) {
   if constexpr (CNT > 0) {
     constexpr int C = CNT < BC ? CNT : BC;
-    chol_update_chunk<K, J0>(a, std::make_integer_sequence<int, C>{});
-    chol_update<K, J0 + C, CNT - C>(a);
+    chol_update_chunk<LB, K, J0>(a, sL, std::make_integer_sequence<int, C>{});
+    chol_update<LB, K, J0 + C, CNT - C>(a, sL);
   }
 }
 // sx -= sum_u L(I, L0 + u) x[L0 + u] (FWD: L(I, l) is lane I's a[l]) resp. L(L0 + u, I) x[L0 + u] (lane L0 + u's a[I])
-template <bool FWD, int I, int L0, int NJ, int... U>
-__device__ __forceinline__ void subst_chunk(const double (&a)[NJ], const double (&x)[NJ], double& sx, std::integer_sequence<int, U...>) {
-  const double l[] = {(FWD ? lane_bcast(a[L0 + U], I) : lane_bcast(a[I], L0 + U))...};
+template <bool LB, bool FWD, int I, int L0, int NJ, int... U>
+__device__ __forceinline__ void subst_chunk(const double (&a)[NJ], const double* sL, const double (&x)[NJ], double& sx, std::integer_sequence<int, U...>) {
+  constexpr int LD = NJ | 1;
+  const double l[] = {(LB ? (FWD ? sL[I + (L0 + U) * LD] : sL[(L0 + U) + I * LD]) : (FWD ? lane_bcast(a[L0 + U], I) : lane_bcast(a[I], L0 + U)))...};
   ((sx -= l[U] * x[L0 + U]), ...);
   value_fence(sx);
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (LB) batch_fence(); else __builtin_amdgcn_sched_barrier(0);
 }
-template <bool FWD, int I, int L0, int CNT, int NJ>
-__device__ __forceinline__ void subst_range(const double (&a)[NJ], const double (&x)[NJ], double& sx) {
+template <bool LB, bool FWD, int I, int L0, int CNT, int NJ>
+__device__ __forceinline__ void subst_range(const double (&a)[NJ], const double* sL, const double (&x)[NJ], double& sx) {
   if constexpr (CNT > 0) {
     constexpr int C = CNT < BC ? CNT : BC;
-    subst_chunk<FWD, I, L0>(a, x, sx, std::make_integer_sequence<int, C>{});
-    subst_range<FWD, I, L0 + C, CNT - C>(a, x, sx);
+    subst_chunk<LB, FWD, I, L0>(a, sL, x, sx, std::make_integer_sequence<int, C>{});
+    subst_range<LB, FWD, I, L0 + C, CNT - C>(a, sL, x, sx);
   }
 }
-template <int K, int NJ>
-__device__ __forceinline__ void chol_steps(double (&a)[NJ], double& my_dinv, int r) {
+template <bool LB, int K, int NJ>
+__device__ __forceinline__ void chol_steps(double (&a)[NJ], double* sL, double& my_dinv, int r) {
   if constexpr (K < NJ) {
+    constexpr int LD = NJ | 1;
     const double dk_own = sqrt(a[K]), di_own = 1.0 / dk_own;
     const double dk = lane_bcast(dk_own, K), dinv_k = lane_bcast(di_own, K);
     my_dinv = (r == K) ? di_own : my_dinv;
     a[K] = (r == K) ? dk : a[K] * dinv_k;
-    chol_update<K, K + 1, NJ - K - 1>(a);
-    chol_steps<K + 1>(a, my_dinv, r);
+    if constexpr (LB) {
+      if (r < NJ) sL[r + K * LD] = a[K];                  // column K of L (the entries above the diagonal: junk nobody reads)
+      batch_fence();
+    }
+    chol_update<LB, K, K + 1, NJ - K - 1>(a, sL);
+    chol_steps<LB, K + 1>(a, sL, my_dinv, r);
   }
 }
-template <int I, int NJ>
-__device__ __forceinline__ void fwd_rows(const double (&a)[NJ], double (&x)[NJ], double my_dinv) {
+template <bool LB, int I, int NJ>
+__device__ __forceinline__ void fwd_rows(const double (&a)[NJ], const double* sL, double (&x)[NJ], double my_dinv) {
   if constexpr (I < NJ) {
     double sx = x[I];
-    subst_range<true, I, 0, I>(a, x, sx);
+    subst_range<LB, true, I, 0, I>(a, sL, x, sx);
     x[I] = sx * lane_bcast(my_dinv, I);
     value_fence(x[I]);
-    fwd_rows<I + 1>(a, x, my_dinv);
+    fwd_rows<LB, I + 1>(a, sL, x, my_dinv);
   }
 }
-template <int I, int NJ>
-__device__ __forceinline__ void bwd_rows(const double (&a)[NJ], double (&x)[NJ], double my_dinv) {
+template <bool LB, int I, int NJ>
+__device__ __forceinline__ void bwd_rows(const double (&a)[NJ], const double* sL, double (&x)[NJ], double my_dinv) {
   if constexpr (I >= 0) {
     double sx = x[I];
-    subst_range<false, I, I + 1, NJ - I - 1>(a, x, sx);
+    subst_range<LB, false, I, I + 1, NJ - I - 1>(a, sL, x, sx);
     x[I] = sx * lane_bcast(my_dinv, I);
     value_fence(x[I]);
-    bwd_rows<I - 1>(a, x, my_dinv);
+    bwd_rows<LB, I - 1>(a, sL, x, my_dinv);
   }
 }
-template <int NJ>
-__device__ __forceinline__ void wave_spd_inverse(double (&a)[NJ], double (&x)[NJ], int r) {
+template <bool LB, int NJ>
+__device__ __forceinline__ void wave_spd_inverse(double (&a)[NJ], double (&x)[NJ], int r, double* sL) {
   double my_dinv = 0.0;                                   // 1 / L(r, r)
-  chol_steps<0>(a, my_dinv, r);
+  chol_steps<LB, 0>(a, sL, my_dinv, r);
   // (the substitutions broadcast the same L(i, l) the factorisation did; the fences keep the compiler from parking all nv^2 / 2
   // of them in spilled scalars to save the second and third v_readlane)
 #pragma unroll
   for (int i = 0; i < NJ; ++i) value_fence(a[i]);
 #pragma unroll
   for (int i = 0; i < NJ; ++i) x[i] = (i == r) ? 1.0 : 0.0;
-  fwd_rows<0>(a, x, my_dinv);
+  fwd_rows<LB, 0>(a, sL, x, my_dinv);
 #pragma unroll
   for (int i = 0; i < NJ; ++i) value_fence(a[i]);
-  bwd_rows<NJ - 1>(a, x, my_dinv);
+  bwd_rows<LB, NJ - 1>(a, sL, x, my_dinv);
+  if constexpr (LB) batch_fence();                        // the image of L is dead: M^-1 goes over it
 }
 
 #ifdef DEV_ANA_CLOCKS   // development: cycle stamps of one wave per launch
@@ -486,7 +503,7 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
         for (int k = 0; k < NJ; ++k) arow[k] = (k == r) ? 1.0 : 0.0;
       }
       double x[NJ];
-      wave_spd_inverse<NJ>(arow, x, r);
+      wave_spd_inverse<INV_LDS, NJ>(arow, x, r, s_Mi);     // (the image of L sits where M^-1 goes afterwards)
       double* Mg = ap.Fws ? ap.Mws + (sbt * (N + 1) + pp) * (int64_t)N * N : nullptr;   // the constraint chain reads M^-1(q') (ana_eq_kernel)
       double* M0g = (ap.stage == 0 && ap.M0) ? ap.M0 + bt * (int64_t)N * N : nullptr;
       if (live) {
