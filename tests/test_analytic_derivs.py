@@ -278,3 +278,35 @@ def test_analytic_whole_solve_talos_drivers_mode(gpu):
     assert log["mu"][0] == log_ref["mu"] and log["reg"][0] == log_ref["reg"]
     assert float(np.max(np.abs(xs - xs_ref))) < 2e-2, float(np.max(np.abs(xs - xs_ref)))
     assert float(np.max(np.abs(us - us_ref))) < 2.0 * max(1.0, float(np.max(np.abs(us_ref))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("tree38_config", 3), ("tree38_frame", 4), ("tree38", 3)])
+def test_fused_evaluation_kernel_against_the_three_kernel_form(gpu, monkeypatch, name, T):
+    """lin_analytic.hip has ONE arithmetic in three arrangements: the fused kernel (an evaluation goes from the state to its tensor
+    slabs inside one wave; the config constraint's tensors come out of the same wave), the fused kernel with the constraint
+    chain in its own kernel (DDP_HIP_ANA_EQ_KERNEL=1, what the frame constraint uses), and the three-kernel form with HBM
+    workspaces (DDP_HIP_ANA_SPLIT=1).  Every output must agree bit for bit."""
+    capi = gpu
+    model, spec, o = make(name, T, batch=2, fd_mode=1, first_order_fd=0)
+    trajs = [held_trajectory(o, model, seed=5 + b, u_sigma=0.3) for b in range(2)]
+    keys = ("FX", "FU", "FXX", "FUX", "FUU", "EQ_VAL", "EQ_X", "EQ_U", "EQ_XX", "EQ_UX", "EQ_UU")
+
+    def run():
+        with capi.Context(spec) as ctx:
+            ctx.upload("X", np.stack([tr[2] for tr in trajs])); ctx.upload("U", np.stack([tr[1] for tr in trajs]))
+            ctx.linearize()
+            return {k: ctx.download(k, 0, 2) for k in keys if ctx.seq_size(k)}
+    fused = run()
+    monkeypatch.setenv("DDP_HIP_ANA_EQ_KERNEL", "1")
+    eqk = run()
+    monkeypatch.delenv("DDP_HIP_ANA_EQ_KERNEL")
+    monkeypatch.setenv("DDP_HIP_ANA_SPLIT", "1")
+    split = run()
+    monkeypatch.delenv("DDP_HIP_ANA_SPLIT")
+    for k in fused:
+        assert np.all(np.isfinite(fused[k])), k
+        assert np.array_equal(fused[k], eqk[k]), (k, "constraint chain in its own kernel")
+        assert np.array_equal(fused[k], split[k]), (k, "three-kernel form")
+    if "EQ_UU" in fused and name == "tree38_config":
+        assert not np.any(fused["EQ_UU"]) and float(np.max(np.abs(fused["EQ_XX"]))) > 0
