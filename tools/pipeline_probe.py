@@ -1,44 +1,63 @@
-"""development probe: P contexts (S/P seeds each) driven from P host threads, staggered by half an iteration"""
-import os, sys, time, threading
+"""development: do two half-batches on contexts (streams) of their own, driven by two host threads, overlap?  One half's
+linearisation (throughput-bound: fills the GPU) should hide the other half's backward + forward sweeps (latency-bound: a few
+hundred waves).  usage: pipeline_probe.py <seeds> <groups> <fd_mode> [iters]"""
+import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from ddp_pinocchio_amd import capi
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-P = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-T = 200
+S, G, MODE = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+T, nv = 200, 38
 model = capi.BuiltinModel(capi.BUILTIN_TREE38, 1)
-ctxs = []
-for k in range(P):
-    s = S // P
-    ctx = capi.Context(capi.ProblemSpec(model, T, batch=s, fd_mode=2))
-    us = 0.1 * np.random.default_rng(k).normal(size=(s, T * 38))
-    ctx.upload("X", np.zeros((s, (T + 1) * 76))); ctx.upload("U", us); ctx.rollout()
+
+
+def make(seeds):
+    spec = capi.ProblemSpec(model, T, dt=0.01, c=1.0, batch=len(seeds), fd_mode=MODE, first_order_fd=0 if MODE == 1 else 1)
+    ctx = capi.Context(spec)
+    us = np.stack([0.1 * np.random.default_rng(0xDD9000 + 3000 + g).normal(size=T * nv) for g in seeds])
+    ctx.upload("X", np.zeros((len(seeds), (T + 1) * 2 * nv))); ctx.upload("U", us); ctx.rollout()
     ctx.upload("X_NEW", ctx.download("X")); ctx.upload("U_NEW", us)
-    ctxs.append(ctx)
-def run(k, steps, start_evt, lin_done):
-    ctx = ctxs[k]; s = S // P
-    reg = np.zeros(s); mu = np.full(s, 1e2)
-    start_evt.wait()
-    for it in range(steps):
-        ctx.linearize()
-        lin_done.set()
-        rc, reg, mu, r = ctx.backward(reg, mu)
-        rc, step, dc = ctx.forward(mu, n_alpha=8)
-        ctx.swap_traj()
-def go(steps):
-    evts = [threading.Event() for _ in range(P)]
-    lins = [threading.Event() for _ in range(P)]
-    th = [threading.Thread(target=run, args=(k, steps, evts[k], lins[k])) for k in range(P)]
-    for t in th: t.start()
-    t0 = time.perf_counter()
-    evts[0].set()
-    for k in range(1, P):
-        lins[k - 1].wait()      # stagger: context k starts when context k-1 has finished its first linearisation
-        evts[k].set()
-    for t in th: t.join()
-    return time.perf_counter() - t0
-go(1)
-el = go(STEPS)
-print(f"S={S} P={P} steps={STEPS}: {el / STEPS * 1e3:.1f} ms/step  {S * STEPS / el:.1f} it/s")
+    return ctx
+
+
+class It:
+    def __init__(self, ctx, n):
+        self.ctx, self.reg, self.mu = ctx, np.zeros(n), np.full(n, 1e2)
+
+    def step(self):
+        c = self.ctx
+        c.linearize()
+        rc, self.reg, self.mu, _ = c.backward(self.reg, self.mu)
+        rc, step, dcost = c.forward(self.mu, n_alpha=8)
+        self.reg = np.where(step >= 0.5, np.where(self.reg / 2 < 1e-5, 0.0, self.reg / 2), self.reg)
+        c.swap_traj()
+
+
+per = S // G
+its = [It(make(list(range(g * per, (g + 1) * per))), per) for g in range(G)]
+for it in its:
+    it.step()
+for it in its:
+    it.ctx.synchronize()
+
+
+STAGGER = float(sys.argv[5]) * 1e-3 if len(sys.argv) > 5 else 0.0
+
+
+def run(it, k, delay=0.0):
+    if delay:
+        time.sleep(delay)
+    for _ in range(k):
+        it.step()
+    it.ctx.synchronize()
+
+
+t0 = time.perf_counter()
+ths = [threading.Thread(target=run, args=(it, K, g * STAGGER)) for g, it in enumerate(its)]
+for t in ths:
+    t.start()
+for t in ths:
+    t.join()
+el = time.perf_counter() - t0
+print(f"seeds {S} groups {G} mode {MODE}: {S * K / el:.1f} iterations/s, {el / K * 1e3:.1f} ms per iteration of all seeds")
