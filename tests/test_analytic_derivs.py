@@ -310,3 +310,28 @@ def test_fused_evaluation_kernel_against_the_three_kernel_form(gpu, monkeypatch,
         assert np.array_equal(fused[k], split[k]), (k, "three-kernel form")
     if "EQ_UU" in fused and name == "tree38_config":
         assert not np.any(fused["EQ_UU"]) and float(np.max(np.abs(fused["EQ_XX"]))) > 0
+
+
+@pytest.mark.gpu
+def test_mode1_linearise_is_reproducible_run_to_run(gpu):
+    """The fused evaluation kernel orders its LDS traffic by program order alone (its work-group is one wave: no s_barrier) and
+    keeps prefetched global reads in flight across phases.  A race would show as run-to-run differences: eight linearisations of
+    the same (T = 40, 3 instances, constrained) problem must give the same bits every time."""
+    capi = gpu
+    T, B = 40, 3
+    model, spec, o = make("tree38_config", T, batch=B, fd_mode=1, first_order_fd=0)
+    rng = np.random.default_rng(11)
+    us = 0.1 * rng.normal(size=(B, T * o.m))
+    with capi.Context(spec) as ctx:
+        ctx.upload("X", np.zeros((B, (T + 1) * o.nx))); ctx.upload("U", us); ctx.rollout()
+        ref = None
+        for rep in range(8):
+            ctx.fill("FXX", float("nan")); ctx.fill("FUX", float("nan")); ctx.fill("EQ_XX", float("nan")); ctx.fill("EQ_UX", float("nan"))
+            ctx.linearize()
+            got = {k: ctx.download(k) for k in ("FX", "FU", "FXX", "FUX", "FUU", "EQ_X", "EQ_U", "EQ_XX", "EQ_UX", "EQ_UU")}
+            assert all(np.all(np.isfinite(v)) for v in got.values())
+            if ref is None:
+                ref = got
+            else:
+                for k in got:
+                    assert np.array_equal(got[k], ref[k]), (k, rep)
