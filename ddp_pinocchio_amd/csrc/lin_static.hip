@@ -1482,15 +1482,15 @@ __global__ __launch_bounds__(LBS, 2) void lin_static_qvcache_kernel(LinParams p,
   constexpr int nv = T::N, n = 2 * nv, MAXCH = max_chain<T>();
   const int lane = threadIdx.x;
   const int64_t Tn = p.d.T;
-  // the base configuration alone (first-order-only contexts, the accelerations of the analytic mode-1 pass): a lane per (instance, t),
-  // 64 of them per wave -- with a wave per (instance, t) 63 of its lanes would idle through a 38-joint latency chain
-  const bool base_only = p.ncfg == 1;
-  const int64_t bt = base_only ? (int64_t)blockIdx.x * LBS + lane : (int64_t)blockIdx.x;
-  const int cfgi = base_only ? 0 : lane;
+  // a lane per (instance, t, configuration), 64 per wave: with a wave per (instance, t) 25 of its lanes (ncfg = nv + 1) or 63 of them
+  // (the base configuration alone: first-order-only contexts, the accelerations of the analytic mode-1 pass) idle through a 38-joint chain
+  const int64_t e = (int64_t)blockIdx.x * LBS + lane;    // evaluation: (instance, t) x configuration, 64 per wave whatever ncfg is
+  const int64_t bt = e / p.ncfg;
+  const int cfgi = (int)(e - bt * p.ncfg);
   const int b = (int)(bt / Tn);
   const int64_t t = bt % Tn;
   __shared__ double s_vel[MAXCH * 6 * LBS];
-  if (base_only ? bt >= p.d.batch * Tn : lane >= p.ncfg) return;   // (no workgroup barrier below)
+  if (bt >= p.d.batch * Tn) return;                       // (no workgroup barrier below)
   QvCtx c;
   c.m = model;
   c.xg = xs + ((int64_t)b * (Tn + 1) + t) * n;
@@ -1581,11 +1581,11 @@ static int lin_static_launch_t(ddp_hip_ctx* ctx, const LinParams& p, int level) 
     hipLaunchKernelGGL((lin_static_tau_kernel<T, true>), dim3((unsigned)(BT * 2 * nv)), dim3(LBS), 0, ctx->stream, p);
     hipLaunchKernelGGL((lin_static_tau_kernel<T, false>), dim3((unsigned)(BT * GU)), dim3(LBS), 0, ctx->stream, p);
   } else if (level == 5) {                        // q- and v-caches
-    hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)(p.ncfg == 1 ? (BT + LBS - 1) / LBS : BT)), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
+    hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)((BT * p.ncfg + LBS - 1) / LBS)), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
     if (p.nvcfg > 1) hipLaunchKernelGGL((lin_static_vcache_kernel<T>), dim3((unsigned)BT), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
   } else if (level == 6 || level == 7) {          // accelerations at x + sqrt(eps_mach) e_k (level 7: and u + sqrt(eps_mach) e_k) -> p.accel_out, after the base caches
     if (!p.accel_out) return DDP_HIP_E_ARG;
-    hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)(p.ncfg == 1 ? (BT + LBS - 1) / LBS : BT)), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
+    hipLaunchKernelGGL((lin_static_qvcache_kernel<T>), dim3((unsigned)((BT * p.ncfg + LBS - 1) / LBS)), dim3(LBS), 0, ctx->stream, p, p.model, p.x, p.qcache, p.vcache);
     const int64_t per = ctx->lin_qws_bt * GU;
     for (int64_t bt0 = 0; bt0 < BT; bt0 += per) {
       const int64_t nb = BT - bt0 < per ? BT - bt0 : per;
