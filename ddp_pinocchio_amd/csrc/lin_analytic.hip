@@ -82,6 +82,9 @@ __device__ __forceinline__ void value_fence(double& v) { asm volatile("" : "+v"(
 // unlike __syncthreads, no wait for the global reads the wave has in flight (the prefetched jacobians)
 static_assert(AW == 64, "wave_sync assumes a one-wave work-group");
 __device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
+// f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ...: a loop whose counter is a template constant in the body
+template <class F, int... Js>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Js...>) { (f(std::integral_constant<int, Js>{}), ...); }
 // the value lane `src` (a constant) holds, as a wave-uniform scalar: two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double lane_bcast(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -567,60 +570,65 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     double* __restrict__ eq_sxx = p.eq_xx + Eb * n * n + (int64_t)(pp - 1) * e_t * n;
     auto products = [&](auto kind_c) {
       constexpr int KIND = decltype(kind_c)::value;
+      // B operand (M^-1) once for all rows of tiles; the A operand (T) of a row of tiles in one batch of LDS reads.  The rows are
+      // software-pipelined: the RTM independent accumulation chains of row jt go to the matrix pipe (16 passes per
+      // v_mfma_f64_16x16x4) while the VALU runs the epilogue of row jt - 1 -- sched_group_barrier interleaves the two streams
+      double bv[RTM][KSM];
 #pragma unroll
-      for (int jt = 0; jt < JTM; ++jt) {
-        if (jt >= JT) continue;
+      for (int sk = 0; sk < KSM; ++sk)
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) {
+          const int l = 4 * sk + l4, rb = 16 * rt + l15;
+          bv[rt][sk] = s_Mi[(rb < N && l < N) ? l + rb * N : 0];
+        }
+#pragma unroll
+      for (int sk = 0; sk < KSM; ++sk)
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) value_fence(bv[rt][sk]);
+      batch_fence();
+#pragma unroll
+      for (int sk = 0; sk < KSM; ++sk)
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) bv[rt][sk] = (16 * rt + l15 < N && 4 * sk + l4 < N) ? bv[rt][sk] : 0.0;
+      double av[2][KSM], oxv[2][(KIND & 8) ? RTM : 1][4];
+      f64x4_ acc[2][RTM];
+      auto load_row = [&](int jt, double (&a_)[KSM], double (&ox_)[(KIND & 8) ? RTM : 1][4]) {
         const int ja = 16 * jt + l15;
-        // all operands of the jt-th row of tiles in one batch of LDS reads, then RTM independent accumulation chains: the matrix
-        // pipe (16 passes per v_mfma_f64_16x16x4) is the only thing this loop should wait for
-        double av[KSM], bv[RTM][KSM];
 #pragma unroll
-        for (int sk = 0; sk < KSM; ++sk) {
-          const int l = 4 * sk + l4;
-          av[sk] = s_T[(ja < W2 && l < N) ? l * W2 + ja : 0];
-#pragma unroll
-          for (int rt = 0; rt < RTM; ++rt) {
-            const int rb = 16 * rt + l15;
-            bv[rt][sk] = s_Mi[(rb < N && l < N) ? l + rb * N : 0];
-          }
-        }
-#pragma unroll
-        for (int sk = 0; sk < KSM; ++sk) {
-          value_fence(av[sk]);
-#pragma unroll
-          for (int rt = 0; rt < RTM; ++rt) value_fence(bv[rt][sk]);
-        }
-        batch_fence();
-        double oxv[(KIND & 8) ? RTM : 1][4];              // eq_x at the lane's entries: requested now, used after the products
-        if constexpr ((KIND & 8) != 0) {
+        for (int sk = 0; sk < KSM; ++sk) a_[sk] = s_T[(ja < W2 && 4 * sk + l4 < N) ? (4 * sk + l4) * W2 + ja : 0];
+        if constexpr ((KIND & 8) != 0) {                  // eq_x at the lane's entries: requested now, used a row later
 #pragma unroll
           for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int j = 16 * jt + l4 + 4 * q, r = 16 * rt + l15;
-              oxv[rt][q] = eqx0[(j < W2 && r < e_t) ? r + j * e_t : 0];
+              ox_[rt][q] = eqx0[(j < W2 && r < e_t) ? r + j * e_t : 0];
             }
         }
-        f64x4_ acc[RTM];
 #pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) acc[rt] = f64x4_{0.0, 0.0, 0.0, 0.0};
+        for (int sk = 0; sk < KSM; ++sk) value_fence(a_[sk]);
+        batch_fence();
 #pragma unroll
-        for (int sk = 0; sk < KSM; ++sk) {
-          const bool lok = 4 * sk + l4 < N;
-          const double a_ = (ja < W2 && lok) ? av[sk] : 0.0;
+        for (int sk = 0; sk < KSM; ++sk) a_[sk] = (ja < W2 && 4 * sk + l4 < N) ? a_[sk] : 0.0;
+      };
+      auto mfma_row = [&](const double (&a_)[KSM], f64x4_ (&c_)[RTM]) {
 #pragma unroll
-          for (int rt = 0; rt < RTM; ++rt) {
-            const double b_ = (16 * rt + l15 < N && lok) ? bv[rt][sk] : 0.0;
-            acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc[rt], 0, 0, 0);
-          }
-        }
+        for (int rt = 0; rt < RTM; ++rt) c_[rt] = f64x4_{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sk = 0; sk < KSM; ++sk)
+#pragma unroll
+          for (int rt = 0; rt < RTM; ++rt)
+            c_[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[sk], bv[rt][sk], c_[rt], 0, 0, 0);   // (a tile beyond nv: zero operands, no branch)
+      };
+      auto epilogue = [&](auto jt_c, const f64x4_ (&c_)[RTM], const double (&ox_)[(KIND & 8) ? RTM : 1][4]) {
+        constexpr int jt = decltype(jt_c)::value;
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int j = 16 * jt + l4 + 4 * q;           // column of the jacobian block (0 .. 2nv-1: q then v directions)
             const int r = 16 * rt + l15;                  // row (joint)
-            double val = (-acc[rt][q]) * dt;              // first_order_deriv, problem.hpp:499-501
+            double val = (-c_[rt][q]) * dt;               // first_order_deriv, problem.hpp:499-501
             val = (j >= N && j - N == r) ? val + 1.0 : val;
             value_fence(val);                             // the jacobian entry as the reference rounds it, before it is differenced (no fused multiply-subtract)
             double bq;
@@ -635,13 +643,27 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
                 if (r < e_t) {
                   const double first = j < N ? ((r == j) ? 1.0 : 0.0) * 1.0 : ((r == j - N) ? 1.0 : 0.0) * (1.0 * dt);
                   const double eqv = fma(dtK, val, first);               // ana_eq_kernel: sacc = first; sacc += C1(i, nv + i) Fv(i, j)
-                  eq_sxx[r + j * e_t] = (eqv - oxv[rt][q]) / eps;        // problem.hpp:128-134
+                  eq_sxx[r + j * e_t] = (eqv - ox_[rt][q]) / eps;        // problem.hpp:128-134
                 }
               }
             }
           }
         }
-      }
+      };
+      load_row(0, av[0], oxv[0]);
+      auto stage = [&](auto jt_c) {
+        constexpr int jt = decltype(jt_c)::value;         // row jt to the matrix pipe, row jt - 1 through the epilogue, row jt + 1 requested
+        if constexpr (jt < JTM) mfma_row(av[jt & 1], acc[jt & 1]);                 // (a row beyond 2 nv: zero operands, results unused)
+        if constexpr (jt >= 1) { if (jt - 1 < JT) epilogue(std::integral_constant<int, jt - 1>{}, acc[(jt - 1) & 1], oxv[(jt - 1) & 1]); }
+        // one matrix instruction, then the vector instructions that fit under its 16 passes
+#pragma unroll
+        for (int g = 0; g < RTM * KSM; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+        if constexpr (jt + 1 < JTM) load_row(jt + 1, av[(jt + 1) & 1], oxv[(jt + 1) & 1]);
+      };
+      static_for(stage, std::make_integer_sequence<int, JTM + 1>{});
     };
     if (pp == 0) products(std::integral_constant<int, 1>{});
     else if (eqi && ap.write_f) products(std::integral_constant<int, 2 | 8>{});
