@@ -138,6 +138,7 @@ struct ddp_hip_ctx {
   double* ana_T = nullptr;     // analytic-derivative workspace (lin_analytic.hip): T = [dtau/dq | dtau/dv] per evaluation of a slice
   double* ana_M = nullptr;     // ... and M / M^-1 per configuration of a slice
   double* ana_F = nullptr;     // ... and the v rows of f_x at the perturbed points (mode-1 constraint tensors)
+  bool ana_A_fresh = false;    // ana_A was formed by stage 0 of the linearisation call in progress
   bool ana_M0_fresh = false;   // ana_M0 was written by stage 0 of the linearisation call in progress
   bool fuu_zero = false;       // analytic mode 1: F_UU holds the exact zeros lin_analytic.hip left there (cleared by every other writer)
   double* ana_M0 = nullptr;    // [B T][nv][nv] M^-1 at the trajectory points (fused analytic path, mode 1)

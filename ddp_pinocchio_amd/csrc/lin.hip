@@ -823,7 +823,11 @@ int run_linearize(ddp_hip_ctx* ctx, const LinParams& p, uint32_t stages) {
     hipLaunchKernelGGL((lin_base_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
     if (!ctx->model_h.first_order_fd && ctx->model_h.kind == DDP_HIP_MODEL_TREE) {
       if constexpr (small) hipLaunchKernelGGL((lin_first_analytic_small_kernel<NJ>), dim3(blocks_for(BT)), dim3(LBS), 0, ctx->stream, p);
-      else { const int rc_ = lin_analytic_launch(ctx, p, 0, LIN_ANA_F); if (rc_ != DDP_HIP_OK) return rc_; }
+      else {
+        const bool m1_next = fd_mode == 1 && p.has_tensors && (stages & DDP_HIP_LIN_SECOND);
+        const int rc_ = lin_analytic_launch(ctx, p, 0, LIN_ANA_F | (m1_next ? LIN_ANA_ACCEL : 0) | (m1_next && eq_stage ? LIN_ANA_EQ << 4 : 0));
+        if (rc_ != DDP_HIP_OK) return rc_;
+      }
     } else if (ctx->model_h.first_order_fd) {
       if (ctx->lin_static && p.qcache && getenv("DDP_HIP_NO_STATIC_FIRST") == nullptr) { build_caches(); { const int rc_ = lin_static_launch(ctx, p, 0); if (rc_ != DDP_HIP_OK) return rc_; } }
       else hipLaunchKernelGGL((lin_first_kernel<NJ>), dim3(blocks_for(BT * W)), dim3(LBS), 0, ctx->stream, p);
@@ -1018,6 +1022,7 @@ extern "C" int ddp_hip_linearize_stages(ddp_hip_ctx* ctx, uint32_t stages) {
   else if (nv <= 38) rc = run_linearize<38>(ctx, p, stages);
   else rc = run_linearize<64>(ctx, p, stages);
   ctx->ana_M0_fresh = false;
+  ctx->ana_A_fresh = false;
   if (rc != DDP_HIP_OK) return rc;
   END_SYNC(ctx);
   // mode 2 writes one value to both (i, j, k) and (i, k, j) (problem.hpp:283-292), mode 0 leaves zeros: f_xx is symmetric bit

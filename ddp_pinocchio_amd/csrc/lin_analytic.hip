@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int AW = 64;     // lanes per evaluation (one wave)
-constexpr int ANA_F = 1, ANA_EQ = 2;
+constexpr int ANA_F = 1, ANA_EQ = 2, ANA_ACCEL = 4, ANA_EQ_NEXT = ANA_EQ << 4;
 
 struct AnaParams {
   LinParams lp;
@@ -44,6 +44,8 @@ struct AnaParams {
   int32_t pad_;
   double* M0;       // fused path: [B T][nv][nv] M^-1 at the trajectory points (stage 0 writes it, the v directions of stage 1 read it)
   int32_t m0_only;  // fused path, stage 0: form M0 alone (the pre-pass of a stage-1 launch)
+  int32_t accel_base;  // stage 0: `accel` also holds the acceleration of the trajectory point itself (slot 3 nv): no forward dynamics in this launch
+  int32_t pad4_;
   int32_t eq_inline;   // fused path, stage 1, config constraint: eq_xx / eq_ux slabs are written by the evaluation's own wave (no Fws / Mws, no ana_eq launch)
   int32_t pad3_;
   int32_t eq_no_aba;   // ana_eq_kernel: no evaluation of this launch runs forward dynamics (stage 1 with `accel`): no ABA state in LDS
@@ -258,8 +260,8 @@ __global__ __launch_bounds__(AW) void ana_eval_kernel(AnaParams ap) {
     }
   }
   wave_sync();
-  if (ap.accel != nullptr && pp >= 1) {
-    const double* __restrict__ ag = ap.accel + ((int64_t)bt * (3 * N) + (pp - 1)) * N;
+  if (ap.accel != nullptr && (pp >= 1 || ap.accel_base)) {
+    const double* __restrict__ ag = ap.accel + ((int64_t)bt * (3 * N + 1) + (pp >= 1 ? pp - 1 : 3 * N)) * N;
     if (live) s_a[lane] = ag[lane];
   } else {
     rbd::aba_tree_coop<NJ, 1, AW>(m, s_q, s_v, s_tau, s_a, s_R1, 0, lane, true);   // ends with a barrier
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(AW) void ana_eq_kernel(AnaParams ap) {
     const bool last = k == K - 1;
     if (!last) {
       if (k == 0 && dir >= 1 && ap.eq_no_aba) {
-        const double* __restrict__ ag = ap.accel + ((int64_t)bt * (3 * N) + (dir - 1)) * N;
+        const double* __restrict__ ag = ap.accel + ((int64_t)bt * (3 * N + 1) + (dir - 1)) * N;
         for (int i = lane; i < N; i += AW) s_a[i] = ag[i];
         __syncthreads();
       } else {
@@ -1097,15 +1099,23 @@ int launch_t(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags) {
     HIP_TRY(hipMemsetAsync(p.fuu, 0, sizeof(double) * (size_t)(ctx->seq[DDP_HIP_SEQ_FUU].size * d.batch), ctx->stream));
     ctx->fuu_zero = true;
   }
-  if (stage == 1 && ctx->ana_A && ctx->lin_static && p.qcache) {
+  const bool accel_now = stage == 0 && (flags & ANA_ACCEL) != 0 && do_f;
+  if ((stage == 1 || accel_now) && ctx->ana_A && ctx->lin_static && p.qcache) {
     // the forward dynamics of the 2 nv perturbed points: the static first-order kernels evaluate exactly these points
-    // (x + sqrt(eps_mach) e_k) chain-wise from the base point's cache, ~25x cheaper than one cooperative ABA per point
-    LinParams pa = p;
-    pa.accel_out = ctx->ana_A;
-    const int rc_ = lin_static_launch(ctx, pa, do_eq ? 7 : 6);   // the constraint chain also differences along the u directions
-    if (rc_ != DDP_HIP_OK) return rc_;
+    // (x + sqrt(eps_mach) e_k) chain-wise from the base point's cache, ~25x cheaper than one cooperative ABA per point.  When the
+    // mode-1 pass follows in the same linearisation call they are formed ahead of stage 0, which then takes the trajectory point's
+    // own acceleration from the same kernels (the idle lanes of the v-level wave evaluate it) instead of running an ABA per point
+    if (!ctx->ana_A_fresh) {
+      LinParams pa = p;
+      pa.accel_out = ctx->ana_A;
+      const bool with_u = stage == 1 ? do_eq : ((flags & ANA_EQ_NEXT) != 0 && d.Etot > 0);   // the constraint chain also differences along the u directions
+      const int rc_ = lin_static_launch(ctx, pa, with_u ? 7 : 6);
+      if (rc_ != DDP_HIP_OK) return rc_;
+      ctx->ana_A_fresh = accel_now;                       // (lin.hip drops the mark when the linearisation call returns)
+    }
     ap.accel = ctx->ana_A;
-    ap.eq_no_aba = (do_eq && ctx->model_h.eq_advance <= 2) ? 1 : 0;   // K <= 2: the one acceleration a direction needs is in ana_A
+    ap.accel_base = accel_now ? 1 : 0;
+    ap.eq_no_aba = (stage == 1 && do_eq && ctx->model_h.eq_advance <= 2) ? 1 : 0;   // K <= 2: the one acceleration a direction needs is in ana_A
   }
   const int P = stage == 0 ? 1 : 2 * N + 1, C = stage == 0 ? 1 : N + 1;
   if (stage == 0 && !do_f) {
@@ -1186,7 +1196,7 @@ int lin_analytic_setup(ddp_hip_ctx* ctx) {
   if (ctx->ana_split || (m1 && d.Etot > 0)) HIP_TRY(hipMalloc(&ctx->ana_M, sizeof(double) * (size_t)(ctx->ana_nbt * (N + 1) * N * N)));
   if (!ctx->ana_split && m1) HIP_TRY(hipMalloc(&ctx->ana_M0, sizeof(double) * (size_t)(BT * N * N)));
   if (ctx->lin_static && ctx->lin_ws && ctx->model_h.fd_mode == 1 && !(ctx->flags & DDP_HIP_FLAG_NO_TENSORS))
-    HIP_TRY(hipMalloc(&ctx->ana_A, sizeof(double) * (size_t)(BT * 3 * N * N)));
+    HIP_TRY(hipMalloc(&ctx->ana_A, sizeof(double) * (size_t)(BT * (3 * N + 1) * N)));
   if (d.Etot > 0) {
     // the constraint chain on analytic jacobians (ana_eq_kernel): K <= 2 look-ahead steps, see the kernel's header
     if (ctx->model_h.eq_advance < 1 || ctx->model_h.eq_advance > 2) return DDP_HIP_E_UNSUPPORTED;

@@ -24,7 +24,7 @@ struct LinParams {
                             // point but those two is bit for bit the base point's -- so only those two and the rows k >= nv are formed
                             // and stored; the other rows hold the zeros lin.hip: tensor_zero_top_kernel left there
   double* accel_out;     // static first-order kernels, levels 1 and 2: when set, the wave stores the accelerations of its nv perturbed
-                         // points, [pair][3 nv directions: q, v, u][nv], instead of the jacobian columns (lin_analytic.hip: mode 1 reads them)
+                         // points, [pair][3 nv directions: q, v, u | the unperturbed point][nv], instead of the jacobian columns (lin_analytic.hip: mode 1 reads them)
   int32_t ncfg, nvcfg;   // entries per (instance, t) of the q- / v-cache: nv+1 / 2nv+1 with the mode-2 stencil resident,
                          // 1 / 1 when only the first order is formed (tensor-free contexts: base configuration and base (q, v))
 };
@@ -43,4 +43,5 @@ int lin_analytic_setup(ddp_hip_ctx* ctx);
 void lin_analytic_teardown(ddp_hip_ctx* ctx);
 // flags: LIN_ANA_F the dynamics' outputs, LIN_ANA_EQ the constraint chain's (problem.hpp:569-620 on the analytic jacobians)
 constexpr int LIN_ANA_F = 1, LIN_ANA_EQ = 2;
+constexpr int LIN_ANA_ACCEL = 4;   // stage 0: the mode-1 pass follows in this linearisation call -- form its accelerations now and take the trajectory point's from them
 int lin_analytic_launch(ddp_hip_ctx* ctx, const LinParams& p, int stage, int flags);

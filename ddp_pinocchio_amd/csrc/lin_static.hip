@@ -1288,9 +1288,12 @@ __global__ __launch_bounds__(LBS) void lin_static_first_kernel(LinParams p, cons
   const kernarg_t kp = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
   __syncthreads();
   if constexpr (!DIAG) {
-    if (double* ao = kp->accel_out) {           // accelerations of the nv perturbed points of this level ([pair][3 nv directions: q, v, u][nv]), for the analytic mode-1 pass
-      ao += (bt * (3 * nv) + (LEVEL - 1) * nv) * nv;
-      for (int e = lane; e < nv * nv; e += LBS) { const int c = e / nv; ao[e] = s_q[c * (nv + 1) + (e - c * nv)]; }
+    if (double* ao = kp->accel_out) {           // accelerations of the nv perturbed points of this level ([pair][3 nv directions: q, v, u | the point itself][nv]), for the analytic mode-1 pass
+      ao += bt * (3 * nv + 1) * nv;
+      double* al = ao + (LEVEL - 1) * nv * nv;
+      for (int e = lane; e < nv * nv; e += LBS) { const int c = e / nv; al[e] = s_q[c * (nv + 1) + (e - c * nv)]; }
+      // level 2: the idle lanes (no direction of theirs) have evaluated the unperturbed point into the spare row
+      if (LEVEL == 2 && lane < nv) ao[3 * nv * nv + lane] = s_q[nv * (nv + 1) + lane];
       return;
     }
   }

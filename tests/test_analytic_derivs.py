@@ -158,7 +158,7 @@ def test_analytic_linearize_talos(gpu, T):
 def test_mode1_static_accelerations_against_own_forward_dynamics(gpu, monkeypatch):
     """mode 1 on a tree with a static topology takes the accelerations of its 2 nv perturbed points from the static first-order
     kernels (lin_static.hip level 6) instead of one cooperative ABA per point (DDP_HIP_ANA_OWN_ABA=1 keeps the latter): two
-    roundings of the same accelerations, so the tensors agree to a few ulp of the jacobians over eps and f_x, f_u bit for bit"""
+    roundings of the same accelerations, so the tensors agree to a few ulp of the jacobians over eps, f_x to rounding and f_u bit for bit"""
     capi = gpu
     T, B = 5, 2
     model, spec, o = make("tree38", T, batch=B, fd_mode=1, first_order_fd=0)
@@ -175,7 +175,8 @@ def test_mode1_static_accelerations_against_own_forward_dynamics(gpu, monkeypatc
     nv = model.nv
     cond = max(float(np.linalg.cond(o.crba(trajs[0][2][t * 2 * nv:t * 2 * nv + nv]))) for t in range(T))
     jscale = max(1.0, float(np.max(np.abs(out[True]["FX"]))), float(np.max(np.abs(out[True]["FU"]))))
-    assert np.array_equal(out[False]["FX"], out[True]["FX"]) and np.array_equal(out[False]["FU"], out[True]["FU"])
+    # (the trajectory point's own acceleration comes from the static kernels too: f_x differs by its rounding, f_u = dt M^-1 does not)
+    assert rel_err(out[False]["FX"], out[True]["FX"]) < 1e-12 and np.array_equal(out[False]["FU"], out[True]["FU"])
     assert np.array_equal(out[False]["FUU"], out[True]["FUU"])
     for k in ("FXX", "FUX"):
         err = float(np.max(np.abs(out[False][k] - out[True][k])))
